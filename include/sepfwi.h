@@ -1,0 +1,127 @@
+/*
+ * sepfwi.h -- C ABI of libsepfwi.so: MI355X-native 2-D elastic staggered-grid forward/adjoint
+ * propagator (velocity-stress, C-PML, boundary-saving reconstruction, DAS axial-strain receivers).
+ *
+ * This is the drop-in boundary for the hot path of seisfwi/SEP-2023 "TorchFWI-DAS".  Every entry
+ * point names the reference interface it replaces (paths relative to
+ * DAS_Waveform_Inversion/Ops/FWI/ in the reference repository).  Plain pointers and sizes only; no
+ * torch types, no C++ types.  All functions return 0 on success and a negative SEPFWI_E* code on
+ * failure; sepfwi_last_error() then holds a message (the reference printf()s and exit(1)s instead:
+ * Src/utilities.h:28-36, Src/utilities.cu:12-16,237-240).
+ *
+ * Pointer arguments documented as "host or device" may be either: transfers use
+ * hipMemcpyDefault, so a torch CPU tensor's data_ptr and a torch HIP tensor's data_ptr both work.
+ */
+#ifndef SEPFWI_H_
+#define SEPFWI_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEPFWI_OK 0
+#define SEPFWI_EINVAL (-1)   /* bad argument / inconsistent sizes                         */
+#define SEPFWI_EIO (-2)      /* parameter, survey or data file missing / unreadable       */
+#define SEPFWI_ECOURANT (-3) /* Courant number > 1            (Src/utilities.cu:225-241)  */
+#define SEPFWI_EHIP (-4)     /* HIP runtime error (no device, out of memory, launch fault)*/
+#define SEPFWI_EJSON (-5)    /* malformed parameter / survey JSON                         */
+
+/* calc_id values (Src/libCUFD.cu:22-25, Src/Parameter.cpp:125-137) */
+#define SEPFWI_CALC_MISFIT 0   /* forward + residual -> misfit                      */
+#define SEPFWI_CALC_GRADIENT 1 /* + boundary saving, adjoint, gradients             */
+#define SEPFWI_CALC_OBSERVE 2  /* forward only, write Shot_{pr,vx,vz,ett}{id}.bin   */
+
+/* Message of the last failure on the calling thread (never NULL). */
+const char *sepfwi_last_error(void);
+
+/* Library version, e.g. 100 = 0.1.0 */
+int sepfwi_version(void);
+
+/* Number of visible HIP devices, or a negative error code. */
+int sepfwi_device_count(void);
+
+/*
+ * Replaces:  extern "C" void cufd(float *misfit, float *grad_Lambda, float *grad_Mu,
+ *                float *grad_Den, float *grad_stf, const float *Lambda, const float *Mu,
+ *                const float *Den, const float *stf, int calc_id, const int gpu_id,
+ *                const int group_size, const int *shot_ids, const string para_fname)
+ *            Src/libCUFD.h:6-10, Src/libCUFD.cu:32-820
+ * called from Src/Torch_Fwi.cpp:31,86,132.  Same argument order and meaning; std::string became
+ * const char*, void became an error code.
+ *
+ *   Lambda, Mu   [MPa], Den [kg/m^3]: (nz, nx) row-major float32, nz/nx the padded sizes of the
+ *                parameter file (FWI_ops.py:124-127).  Host or device.
+ *   stf          (nSrc, nSteps) row-major; row shot_ids[i] is shot i's source (Src/Src_Rec.cu:9,132).
+ *                Host or device.
+ *   shot_ids     group_size ints, host.
+ *   misfit       1 float (calc_id 0,1): 0.5 * sum over shots of sum r_ett^2 (libCUFD.cu:427,776).
+ *   grad_Lambda, grad_Mu, grad_Den   (nz, nx) row-major, OVERWRITTEN with this call's sum over its
+ *                shots (calc_id 1).  Gradients are w.r.t. MPa for Lambda/Mu.  Host or device.
+ *   grad_stf     (group_size, nSteps): row i = shot_ids[i] (local position, libCUFD.cu:671-673).
+ *   para_fname   one-line JSON written by fwi_utils.paraGen (fwi_utils.py:46-83); names the survey
+ *                JSON (fwi_utils.py:87-124) and the data directory holding
+ *                Shot_{pr,vx,vz,ett}{id}.bin, float32 [nrec][nSteps] (libCUFD.cu:216-223,755-769).
+ *
+ * Unlike the reference, device state (fields, PML profiles, boundary buffers, observed data) is kept
+ * in a per-(para_fname, gpu_id) session between calls; sepfwi_release_all() frees it.
+ */
+int sepfwi_cufd(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den,
+                float *grad_stf, const float *Lambda, const float *Mu, const float *Den,
+                const float *stf, int calc_id, int gpu_id, int group_size, const int *shot_ids,
+                const char *para_fname);
+
+/* Same as sepfwi_cufd, but all launches go to `hip_stream` (a hipStream_t, may be NULL) and the call
+ * returns without a final device synchronisation when `async` != 0 and every output pointer is a
+ * device pointer (misfit, gradients).  Used by bench.py to time with inputs resident in HBM. */
+int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den,
+                       float *grad_stf, const float *Lambda, const float *Mu, const float *Den,
+                       const float *stf, int calc_id, int gpu_id, int group_size,
+                       const int *shot_ids, const char *para_fname, void *hip_stream, int async);
+
+/* Frees every cached session (device memory, cached observed data) of this process. */
+void sepfwi_release_all(void);
+
+/* Drops cached observed data (e.g. after the Shot_*.bin files were rewritten by another tool). */
+void sepfwi_invalidate_observed(void);
+
+/*
+ * Host helpers exported for parity tests (they are what the session uses internally).
+ *   sepfwi_cpml_profiles: the six 1-D C-PML arrays K, a, b, K_half, a_half, b_half of length N.
+ *                         Replaces cpmlInit, Src/utilities.cu:243-359.
+ *   sepfwi_stf_taper:     in-place sin^2/cos^2 taper of one trace.  Replaces the 5-argument
+ *                         cuda_window, Src/utilities.cu:844-884 (ratio 0.001, Src/Src_Rec.cu:137).
+ *   sepfwi_shot_split:    start offsets (ngpu+1 ints) of the contiguous shot blocks per GPU.
+ *                         Replaces the sepBars logic of Src/Torch_Fwi.cpp:59-60,78-80.
+ */
+int sepfwi_cpml_profiles(float *K, float *a, float *b, float *K_half, float *a_half,
+                         float *b_half, int N, int nPml, float dh, float f0, float dt);
+int sepfwi_stf_taper(float *trace, int nt, float dt, float ratio);
+int sepfwi_shot_split(int group_size, int ngpu, int *starts);
+
+/*
+ * Statistics of the most recent sepfwi_cufd* call on (para_fname, gpu_id): kernel time measured
+ * with hipEvents on the session's stream, cell-update counts as defined in SURVEY.md section 8(d).
+ */
+typedef struct sepfwi_stats {
+    double fwd_ms;            /* forward time loops, all shots of the call                    */
+    double bwd_ms;            /* backward (reconstruction + adjoint + imaging) time loops     */
+    double total_ms;          /* whole call, host wall clock                                  */
+    double cell_updates;      /* N_c * (nSteps-1) * shots * (1 or 3)                          */
+    long long fwd_steps;      /* forward time steps executed                                  */
+    long long bwd_steps;      /* backward time steps executed                                 */
+    long long launches;       /* kernel launches issued                                       */
+    long long device_bytes;   /* device memory held by the session                            */
+    int n_c;                  /* computed cells per step (nz-nPad)*(nx)  [PML included]       */
+} sepfwi_stats;
+int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
+
+/*
+ * Kernel-variant selection for A/B measurements.  `name` is e.g. "fwd", "bwd";
+ * value semantics are documented in csrc/kernels.hip.  Returns SEPFWI_EINVAL for unknown names.
+ */
+int sepfwi_set_option(const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEPFWI_H_ */

@@ -1,0 +1,124 @@
+// capi.cpp -- the extern "C" surface declared in include/sepfwi.h.  Exceptions never cross it: every
+// failure becomes an error code plus a thread-local message (the reference printf()s and exit(1)s,
+// Src/utilities.h:28-36, which would take the Python interpreter down).
+#include <cstring>
+#include <string>
+
+#include "session.hpp"
+
+using namespace sepfwi;
+
+static thread_local std::string t_last_error = "";
+
+static int fail(int code, const std::string &msg) {
+    t_last_error = msg;
+    return code;
+}
+
+template <class Fn>
+static int guarded(Fn &&fn) {
+    try {
+        fn();
+        return SEPFWI_OK;
+    } catch (const CourantError &e) {
+        return fail(SEPFWI_ECOURANT, e.what());
+    } catch (const IoError &e) {
+        return fail(SEPFWI_EIO, e.what());
+    } catch (const HipError &e) {
+        return fail(SEPFWI_EHIP, e.what());
+    } catch (const std::invalid_argument &e) {
+        return fail(SEPFWI_EINVAL, e.what());
+    } catch (const std::runtime_error &e) {
+        const char *w = e.what();
+        if (std::strncmp(w, "EIO:", 4) == 0) return fail(SEPFWI_EIO, w + 5);
+        if (std::strncmp(w, "JSON", 4) == 0 || std::strstr(w, "JSON")) return fail(SEPFWI_EJSON, w);
+        return fail(SEPFWI_EINVAL, w);
+    } catch (const std::exception &e) {
+        return fail(SEPFWI_EINVAL, e.what());
+    } catch (...) {
+        return fail(SEPFWI_EINVAL, "unknown failure");
+    }
+}
+
+extern "C" {
+
+const char *sepfwi_last_error(void) { return t_last_error.c_str(); }
+
+int sepfwi_version(void) { return 100; }
+
+int sepfwi_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(SEPFWI_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf,
+                       const float *Lambda, const float *Mu, const float *Den, const float *stf, int calc_id,
+                       int gpu_id, int group_size, const int *shot_ids, const char *para_fname, void *hip_stream,
+                       int async) {
+    return guarded([&] {
+        if (calc_id < 0 || calc_id > 2) throw std::invalid_argument("Invalid calc_id " + std::to_string(calc_id));  // libCUFD.cu:43-46
+        if (!para_fname) throw std::invalid_argument("para_fname is NULL");
+        if (!Lambda || !Mu || !Den || !stf) throw std::invalid_argument("Lambda, Mu, Den and stf must not be NULL");
+        if (group_size < 0 || (group_size > 0 && !shot_ids)) throw std::invalid_argument("bad shot list");
+        if (calc_id == 1 && (!grad_Lambda || !grad_Mu || !grad_Den)) throw std::invalid_argument("gradient outputs must not be NULL for calc_id 1");
+        Session &s = get_session(para_fname, gpu_id);
+        s.run(misfit, grad_Lambda, grad_Mu, grad_Den, grad_stf, Lambda, Mu, Den, stf, calc_id, group_size, shot_ids,
+              (hipStream_t)hip_stream, async != 0);
+    });
+}
+
+int sepfwi_cufd(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf,
+                const float *Lambda, const float *Mu, const float *Den, const float *stf, int calc_id, int gpu_id,
+                int group_size, const int *shot_ids, const char *para_fname) {
+    return sepfwi_cufd_stream(misfit, grad_Lambda, grad_Mu, grad_Den, grad_stf, Lambda, Mu, Den, stf, calc_id, gpu_id,
+                              group_size, shot_ids, para_fname, nullptr, 0);
+}
+
+void sepfwi_release_all(void) {
+    try { release_all_sessions(); } catch (...) {}
+}
+
+void sepfwi_invalidate_observed(void) {
+    try { invalidate_observed_all(); } catch (...) {}
+}
+
+int sepfwi_cpml_profiles(float *K, float *a, float *b, float *K_half, float *a_half, float *b_half, int N, int nPml,
+                         float dh, float f0, float dt) {
+    return guarded([&] {
+        if (!K || !a || !b || !K_half || !a_half || !b_half || N <= 0 || nPml <= 0) throw std::invalid_argument("bad arguments");
+        cpml_profiles(K, a, b, K_half, a_half, b_half, N, nPml, dh, f0, dt);
+    });
+}
+
+int sepfwi_stf_taper(float *trace, int nt, float dt, float ratio) {
+    return guarded([&] {
+        if (!trace || nt <= 0) throw std::invalid_argument("bad arguments");
+        if (!stf_taper(trace, nt, dt, ratio)) throw std::invalid_argument("Window error 2: taper longer than half the trace");
+    });
+}
+
+int sepfwi_shot_split(int group_size, int ngpu, int *starts) {
+    return guarded([&] {
+        if (!starts || ngpu <= 0 || group_size < 0) throw std::invalid_argument("bad arguments");
+        if (ngpu > group_size) throw std::invalid_argument("The number of GPUs should be smaller than the number of shots!");  // Torch_Fwi.cpp:49-52
+        shot_split(group_size, ngpu, starts);
+    });
+}
+
+int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out) {
+    return guarded([&] {
+        if (!para_fname || !out) throw std::invalid_argument("bad arguments");
+        Session *s = find_session(para_fname, gpu_id);
+        if (!s) throw std::invalid_argument("no session for this parameter file / gpu");
+        s->stats(out);
+    });
+}
+
+int sepfwi_set_option(const char *name, int value) {
+    (void)value;
+    return fail(SEPFWI_EINVAL, std::string("unknown option '") + (name ? name : "") + "'");
+}
+
+}  // extern "C"

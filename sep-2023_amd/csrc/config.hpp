@@ -1,0 +1,52 @@
+// config.hpp -- parameter / survey description of one propagation setup.
+// Same JSON schema as the reference (writer: fwi_utils.py:46-124; readers it replaces:
+// Src/Parameter.cpp:17-178 and Src/Src_Rec.cu:20-281).
+#pragma once
+#include <string>
+#include <vector>
+
+namespace sepfwi {
+
+struct Params {
+    int nz = 0, nx = 0;  // padded grid sizes
+    float dz = 0, dx = 0, dt = 0, f0 = 0;
+    int nSteps = 0, nPml = 0, nPad = 0;
+    std::string survey_fname, data_dir_name, scratch_dir_name;
+    bool if_win = false, if_src_update = false, if_cross_misfit = false, has_filter = false;
+};
+
+struct Shot {
+    int z_src = 0, x_src = 0;  // already shifted by +nPml (Src_Rec.cu:87-92)
+    int nrec = 0;
+    std::vector<int> z_rec, x_rec;  // shifted by +nPml (Src_Rec.cu:107-115)
+    double src_rxz = 1.0;           // RSXXZZ default, Src_Rec.cu:259-264
+    bool present = false;
+};
+
+struct Survey {
+    int nShots = 0;
+    std::vector<Shot> shots;  // indexed by shot id ("shot%d" keys)
+    int max_nrec = 0;
+};
+
+// Read the first line of a file (the reference only reads one line: Parameter.cpp:29, Src_Rec.cu:32).
+// Throws std::runtime_error("EIO: ...") if the file cannot be opened.
+std::string read_first_line(const std::string &fname);
+
+// Parse; throw std::runtime_error on malformed input.
+Params parse_params(const std::string &json_text);
+Survey parse_survey(const std::string &json_text, int nPml);
+
+// C-PML 1-D profiles (replaces cpmlInit, Src/utilities.cu:243-359).
+void cpml_profiles(float *K, float *a, float *b, float *K_half, float *a_half, float *b_half, int N, int nPml,
+                   float dh, float f0, float dt);
+
+// sin^2 / cos^2 end taper of a trace (replaces the 5-argument cuda_window, Src/utilities.cu:844-884).
+// Returns false (trace untouched) in the reference's "Window error 2" case.
+bool stf_taper(float *trace, int nt, float dt, float ratio);
+
+// Contiguous split of `group_size` shots over `ngpu` devices (Src/Torch_Fwi.cpp:59-60,78-80):
+// starts[i] = (int) float32 linspace(0, group_size, ngpu+1)[i].
+void shot_split(int group_size, int ngpu, int *starts);
+
+}  // namespace sepfwi

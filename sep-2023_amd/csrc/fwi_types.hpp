@@ -1,0 +1,71 @@
+// fwi_types.hpp -- shared host/device plain structs of the propagator.
+//
+// HBM layout (see DESIGN.md "Data layout"): every 2-D array is row-major with x fastest, i.e. the
+// operator boundary's own (nz, nx) orientation (FWI_ops.py:124-127) -- the reference transposes to
+// z-fastest on the host every call (Src/libCUFD.cu:71-77,718-724); here no transpose is needed.
+// Rows are padded to `pitch` floats (a multiple of 64 -> every row starts on a 256-B line) and only
+// the nzc = nz - nPad rows that are ever computed are stored (Appendix A-5 of SURVEY.md: the nPad
+// bottom rows are dead).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace sepfwi {
+
+struct Grid {
+    int nzc;    // stored/computed rows = nz - nPad
+    int nx;     // padded nx (columns)
+    int pitch;  // floats per stored row
+    int nz;     // padded nz of the boundary arrays (nzc + nPad)
+    int nPml;
+    int zmax;   // last interior row    = nzc - 1 - nPml   (el_stress.cu:92)
+    int xmax;   // last interior column = nx  - 1 - nPml
+    int nSteps;
+    float dt;
+    float rdz, rdx;  // 1/dz, 1/dx
+    float dz, dx;
+    // boundary frame geometry (Boundary.cu:17-27): rows/cols [nPml-2, nPml-2+n?Bnd)
+    int nzBnd, nxBnd;  // nzc - 2 nPml + 4, nx - 2 nPml + 4
+    int frame_len;     // floats per field per time step in OUR packing (no duplicated corners)
+};
+
+// Five wavefields (or their adjoint twins), each nzc*pitch floats.
+struct Fields {
+    float *vz, *vx, *szz, *sxx, *sxz;
+};
+
+// Eight C-PML memory variables.  Forward run: psi of the forward fields; backward run: reused as
+// the adjoint memory variables exactly as the reference does (libCUFD.cu:508-515).
+struct PmlMem {
+    float *dvz_dz, *dvz_dx, *dvx_dz, *dvx_dx;      // updated by the stress kernels
+    float *dszz_dz, *dsxz_dx, *dsxz_dz, *dsxx_dx;  // updated by the velocity kernels
+};
+
+// Media in internal layout, Pa.
+struct Media {
+    const float *lam, *mu, *ave_mu, *byc_a, *byc_b;
+};
+
+// 1-D C-PML profiles; z arrays have nzc entries, x arrays nx entries.  rK = 1/K.
+struct PmlCoef {
+    const float *a_z, *b_z, *rK_z, *a_zh, *b_zh, *rK_zh;
+    const float *a_x, *b_x, *rK_x, *a_xh, *b_xh, *rK_xh;
+};
+
+// Imaging accumulators (race-free gather form of el_stress.cu:108-123 / el_velocity.cu:101-110):
+//   lam : sum_t -(szz_a+sxx_a)(dvz_dz+dvx_dx) dt          at (z,x)
+//   mu  : sum_t -2(szz_a dvz_dz + sxx_a dvx_dx) dt          at (z,x)
+//   xz  : sum_t -sxz_a (dvx_dz+dvz_dx) dt                    at the staggered corner (z+1/2,x+1/2)
+//   a   : sum_t -vz_a (dszz_dz+dsxz_dx) dt                   at the vz point
+//   b   : sum_t -vx_a (dsxz_dz+dsxx_dx) dt                   at the vx point
+// The constant-in-time factors (MEGA, mu-harmonic weights, -byc^2/2) and the 4-/2-point spray are
+// applied once per call by k_finalize_gradients.
+struct ImgAcc {
+    float *lam, *mu, *xz, *a, *b;
+};
+
+struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step
+    float *buf;  // [nSteps][5][frame_len]  order: szz, sxz, sxx, vz, vx (Boundary.cu:57-80)
+};
+
+}  // namespace sepfwi

@@ -1,0 +1,586 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the 2-D elastic propagator.
+//
+// What each kernel replaces in the reference (paths relative to DAS_Waveform_Inversion/Ops/FWI/Src):
+//   k_stress<FWD>    el_stress(isFor=true)   el_stress.cu:50-87    + from_bnd x5 (utilities.cu:362-392,
+//                    Boundary.cu:57-80) + add_source (utilities.cu:524-552)
+//   k_velocity<FWD>  el_velocity(isFor=true) el_velocity.cu:45-82
+//   k_velocity<REV>  el_velocity(isFor=false) el_velocity.cu:87-113 + source_grad (utilities.cu:719-730)
+//                    + to_bnd(vz,vx) (utilities.cu:395-425)
+//   k_stress<REV>    add_source(-) + el_stress(isFor=false) el_stress.cu:92-125 + to_bnd(szz,sxz,sxx)
+//   k_velocity_adj   el_velocity_adj.cu:57-102
+//   k_stress_adj     el_stress_adj.cu:53-97
+//   k_record         recording, recording_vx, recording_vz, recording_exx (utilities.cu:593-602,645-703)
+//   k_inject         res_injection_exx (utilities.cu:605-615)
+//   k_residual       gpuMinus + cuda_cal_objective (utilities.cu:154-205)
+//   k_model_prep     host transpose x MEGA (libCUFD.cu:71-77) + velInit/aveMuInit/aveBycInit
+//                    (utilities.cu:109-152, Model.cu:66-87)
+//   k_finalize_gradients  the atomicAdd sprays of el_stress.cu:112-123 / el_velocity.cu:105-110 in
+//                    gather form, and the D2H transpose of libCUFD.cu:718-724 (not needed here)
+//
+// Arrays are row-major, x fastest, pitch `g.pitch` (fwi_types.hpp).  A wave covers 64 consecutive
+// x of one row, so every global access of a wave is one 256-B line-aligned segment (plus the +-1/+-2
+// shifted re-reads that hit the same lines in the vector L1).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace sepfwi {
+
+namespace {
+
+constexpr float C1 = 9.0f / 8.0f;   // el_stress.cu:42
+constexpr float C2 = 1.0f / 24.0f;  // el_stress.cu:43
+constexpr int BX = 64;              // threads along x  (one wave)
+constexpr int BZ = 4;               // waves per block, one row each
+
+// backward-staggered first derivative D-:  (c1 (f0 - fm1) - c2 (fp1 - fm2)) / h
+__device__ __forceinline__ float dminus(float fm2, float fm1, float f0, float fp1, float rh) {
+    return (C1 * (f0 - fm1) - C2 * (fp1 - fm2)) * rh;
+}
+// forward-staggered first derivative D+:   (c1 (fp1 - f0) - c2 (fp2 - fm1)) / h
+__device__ __forceinline__ float dplus(float fm1, float f0, float fp1, float fp2, float rh) {
+    return (C1 * (fp1 - f0) - C2 * (fp2 - fm1)) * rh;
+}
+
+// Slot of cell (z,x) in the packed boundary frame, or -1.  The frame is the 5-cell-thick ring
+// rows/cols [nPml-2, nPml+2] U [n-nPml-3, n-nPml+1] of the reference (utilities.cu:362-392) without
+// its duplicated corners:  [top 5 rows][bottom 5 rows][middle rows: 5 left + 5 right cells].
+__device__ __forceinline__ int frame_slot(const Grid &g, int z, int x) {
+    const int zf = z - (g.nPml - 2), xf = x - (g.nPml - 2);
+    if (zf < 0 || zf >= g.nzBnd || xf < 0 || xf >= g.nxBnd) return -1;
+    if (zf < 5) return zf * g.nxBnd + xf;
+    if (zf >= g.nzBnd - 5) return (5 + zf - (g.nzBnd - 5)) * g.nxBnd + xf;
+    const int base = 10 * g.nxBnd + (zf - 5) * 10;
+    if (xf < 5) return base + xf;
+    if (xf >= g.nxBnd - 5) return base + 5 + (xf - (g.nxBnd - 5));
+    return -1;
+}
+
+__device__ __forceinline__ bool in_pml_z(const Grid &g, int z) { return z < g.nPml || z > g.nzc - g.nPml - 1; }
+
+struct Cell {
+    int z, x;
+    size_t i;  // z*pitch + x
+};
+
+__device__ __forceinline__ Cell my_cell(const Grid &g) {
+    Cell c;
+    c.x = blockIdx.x * BX + (threadIdx.x & (BX - 1));
+    // row is wave-uniform: keep it in an SGPR so the z-profile loads and PML tests are scalar
+    c.z = __builtin_amdgcn_readfirstlane(blockIdx.y * BZ + (threadIdx.x >> 6));
+    c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
+    return c;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// stress update
+// ---------------------------------------------------------------------------------------------
+template <bool FWD, bool SAVE>
+__global__ __launch_bounds__(BX *BZ) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
+                                                   float *__restrict__ frame_t,  // this step's 5*frame_len block
+                                                   int z_src, int x_src, float src_amp,  // scale*stf[it]*dt
+                                                   Fields adj, ImgAcc acc) {
+    const Cell c = my_cell(g);
+    const int z = c.z, x = c.x, P = g.pitch;
+    if (z >= g.nzc || x >= g.nx) return;
+    const size_t i = c.i;
+
+    if constexpr (FWD) {
+        if constexpr (SAVE) {
+            // boundary saving BEFORE this step's update (libCUFD.cu:271-273)
+            const int s = frame_slot(g, z, x);
+            if (s >= 0) {
+                const int L = g.frame_len;
+                frame_t[s] = f.szz[i];
+                frame_t[L + s] = f.sxz[i];
+                frame_t[2 * L + s] = f.sxx[i];
+                frame_t[3 * L + s] = f.vz[i];
+                frame_t[4 * L + s] = f.vx[i];
+            }
+        }
+        if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_stress.cu:52
+
+        float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
+        float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
+        float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
+        float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
+
+        if (in_pml_z(g, z)) {  // wave-uniform branch
+            float p = pc.b_z[z] * m.dvz_dz[i] + pc.a_z[z] * dvz_dz;
+            m.dvz_dz[i] = p;
+            dvz_dz = dvz_dz * pc.rK_z[z] + p;
+            float q = pc.b_zh[z] * m.dvx_dz[i] + pc.a_zh[z] * dvx_dz;
+            m.dvx_dz[i] = q;
+            dvx_dz = dvx_dz * pc.rK_zh[z] + q;
+        }
+        if (x < g.nPml || x > g.nx - g.nPml - 1) {  // el_stress.cu:61,77
+            float p = pc.b_x[x] * m.dvx_dx[i] + pc.a_x[x] * dvx_dx;
+            m.dvx_dx[i] = p;
+            dvx_dx = dvx_dx * pc.rK_x[x] + p;
+            float q = pc.b_xh[x] * m.dvz_dx[i] + pc.a_xh[x] * dvz_dx;
+            m.dvz_dx[i] = q;
+            dvz_dx = dvz_dx * pc.rK_xh[x] + q;
+        }
+        const float lam = md.lam[i], mu = md.mu[i];
+        const float l2m = lam + 2.0f * mu;
+        float szz = f.szz[i] + (l2m * dvz_dz + lam * dvx_dx) * g.dt;
+        float sxx = f.sxx[i] + (lam * dvz_dz + l2m * dvx_dx) * g.dt;
+        if (z == z_src && x == x_src) {  // add_source, utilities.cu:531-538
+            szz += src_amp;
+            sxx += src_amp;
+        }
+        f.szz[i] = szz;
+        f.sxx[i] = sxx;
+        f.sxz[i] += md.ave_mu[i] * (dvx_dz + dvz_dx) * g.dt;
+    } else {
+        // ---- reverse-time reconstruction + lambda/mu imaging ----
+        const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
+        const int s = frame_slot(g, z, x);
+        if (!interior && s < 0) return;
+        float szz = 0.f, sxx = 0.f, sxz = 0.f;
+        if (interior) {
+            szz = f.szz[i];
+            sxx = f.sxx[i];
+            sxz = f.sxz[i];
+            if (z == z_src && x == x_src) {  // add_source(isFor=false) comes first (libCUFD.cu:566-569)
+                szz -= src_amp;
+                sxx -= src_amp;
+            }
+            const float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
+            const float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
+            const float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
+            const float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
+            const float lam = md.lam[i], mu = md.mu[i];
+            const float l2m = lam + 2.0f * mu;
+            szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
+            sxx -= (lam * dvz_dz + l2m * dvx_dx) * g.dt;
+            sxz -= md.ave_mu[i] * (dvx_dz + dvz_dx) * g.dt;
+            // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
+            const float za = adj.szz[i], xa = adj.sxx[i], sa = adj.sxz[i];
+            acc.lam[i] += -(za + xa) * (dvz_dz + dvx_dx) * g.dt;
+            acc.mu[i] += -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt;
+            acc.xz[i] += -sa * (dvx_dz + dvz_dx) * g.dt;
+        }
+        if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
+            const int L = g.frame_len;
+            szz = frame_t[s];
+            sxz = frame_t[L + s];
+            sxx = frame_t[2 * L + s];
+        }
+        f.szz[i] = szz;
+        f.sxx[i] = sxx;
+        f.sxz[i] = sxz;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// velocity update
+// ---------------------------------------------------------------------------------------------
+template <bool FWD>
+__global__ __launch_bounds__(BX *BZ) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
+                                                     const float *__restrict__ frame_t, int z_src, int x_src,
+                                                     float src_rxz, float *__restrict__ stf_grad_it,
+                                                     Fields adj, ImgAcc acc) {
+    const Cell c = my_cell(g);
+    const int z = c.z, x = c.x, P = g.pitch;
+    if (z >= g.nzc || x >= g.nx) return;
+    const size_t i = c.i;
+
+    if constexpr (FWD) {
+        if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_velocity.cu:47
+        float dszz_dz = dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
+        float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
+        float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
+        float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+        if (in_pml_z(g, z)) {
+            float p = pc.b_zh[z] * m.dszz_dz[i] + pc.a_zh[z] * dszz_dz;
+            m.dszz_dz[i] = p;
+            dszz_dz = dszz_dz * pc.rK_zh[z] + p;
+            float q = pc.b_z[z] * m.dsxz_dz[i] + pc.a_z[z] * dsxz_dz;
+            m.dsxz_dz[i] = q;
+            dsxz_dz = dsxz_dz * pc.rK_z[z] + q;
+        }
+        if (x < g.nPml || x > g.nx - g.nPml) {  // el_velocity.cu:56,71 (one column narrower on the right)
+            float p = pc.b_x[x] * m.dsxz_dx[i] + pc.a_x[x] * dsxz_dx;
+            m.dsxz_dx[i] = p;
+            dsxz_dx = dsxz_dx * pc.rK_x[x] + p;
+            float q = pc.b_xh[x] * m.dsxx_dx[i] + pc.a_xh[x] * dsxx_dx;
+            m.dsxx_dx[i] = q;
+            dsxx_dx = dsxx_dx * pc.rK_xh[x] + q;
+        }
+        f.vz[i] += (dszz_dz + dsxz_dx) * md.byc_a[i] * g.dt;
+        f.vx[i] += (dsxz_dz + dsxx_dx) * md.byc_b[i] * g.dt;
+    } else {
+        // source_grad uses the adjoint stresses as they stand at the start of the step (libCUFD.cu:547)
+        if (z == z_src && x == x_src) *stf_grad_it = -(adj.szz[i] + src_rxz * adj.sxx[i]) * g.dt;
+        const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
+        const int s = frame_slot(g, z, x);
+        if (!interior && s < 0) return;
+        float vz = 0.f, vx = 0.f;
+        if (interior) {
+            const float dszz_dz = dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
+            const float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
+            const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
+            const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+            vz = f.vz[i] - (dszz_dz + dsxz_dx) * md.byc_a[i] * g.dt;
+            vx = f.vx[i] - (dsxz_dz + dsxx_dx) * md.byc_b[i] * g.dt;
+            // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
+            acc.a[i] += -adj.vz[i] * (dszz_dz + dsxz_dx) * g.dt;
+            acc.b[i] += -adj.vx[i] * (dsxz_dz + dsxx_dx) * g.dt;
+        }
+        if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
+            const int L = g.frame_len;
+            vz = frame_t[3 * L + s];
+            vx = frame_t[4 * L + s];
+        }
+        f.vz[i] = vz;
+        f.vx[i] = vx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint velocity update.  el_velocity_adj.cu:57-102.  `f` holds the ADJOINT fields.
+// The a*dpsi terms are evaluated only where a != 0 (inside the PML strips; a is exactly 0 elsewhere,
+// utilities.cu:272-275,347-353), which lets k_stress_adj keep psi only near the strips.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BX *BZ) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    const Cell c = my_cell(g);
+    const int z = c.z, x = c.x, P = g.pitch;
+    if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
+    const size_t i = c.i;
+    const bool pz = in_pml_z(g, z);
+    const bool px = (x < g.nPml || x > g.nx - g.nPml - 1);
+    const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
+    const float l2m = lam + 2.0f * mu;
+    const float rKx = pc.rK_x[x], rKxh = pc.rK_xh[x], rKz = pc.rK_z[z], rKzh = pc.rK_zh[z];
+
+    // vx
+    const float dszz_dx = -dplus(f.szz[i - 1], f.szz[i], f.szz[i + 1], f.szz[i + 2], g.rdx);
+    const float dsxx_dx = -dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+    const float dsxz_dz = -dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
+    float upd = lam * dszz_dx * rKx * g.dt + l2m * dsxx_dx * rKx * g.dt + amu * rKzh * dsxz_dz * g.dt;
+    if (px) upd += pc.a_x[x] * -dplus(m.dvx_dx[i - 1], m.dvx_dx[i], m.dvx_dx[i + 1], m.dvx_dx[i + 2], g.rdx);
+    if (pz) upd += pc.a_zh[z] * -dminus(m.dvx_dz[i - 2 * P], m.dvx_dz[i - P], m.dvx_dz[i], m.dvx_dz[i + P], g.rdz);
+    const float vx = f.vx[i] + upd;
+    f.vx[i] = vx;
+    const float bb = md.byc_b[i];
+    if (px) m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
+    if (pz) m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
+
+    // vz
+    const float dszz_dz = -dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
+    const float dsxx_dz = -dplus(f.sxx[i - P], f.sxx[i], f.sxx[i + P], f.sxx[i + 2 * P], g.rdz);
+    const float dsxz_dx = -dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
+    float upz = l2m * dszz_dz * rKz * g.dt + lam * dsxx_dz * rKz * g.dt + amu * rKxh * dsxz_dx * g.dt;
+    if (pz) upz += pc.a_z[z] * -dplus(m.dvz_dz[i - P], m.dvz_dz[i], m.dvz_dz[i + P], m.dvz_dz[i + 2 * P], g.rdz);
+    if (px) upz += pc.a_xh[x] * -dminus(m.dvz_dx[i - 2], m.dvz_dx[i - 1], m.dvz_dx[i], m.dvz_dx[i + 1], g.rdx);
+    const float vz = f.vz[i] + upz;
+    f.vz[i] = vz;
+    const float ba = md.byc_a[i];
+    if (px) m.dsxz_dx[i] = pc.b_x[x] * m.dsxz_dx[i] + ba * vz * g.dt;
+    if (pz) m.dszz_dz[i] = pc.b_zh[z] * m.dszz_dz[i] + ba * vz * g.dt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint stress update.  el_stress_adj.cu:53-97.  The reference updates the four psi arrays over
+// the whole domain (strip tests commented out, :67-72,:88-95); they are only ever READ through
+// stencils multiplied by a (zero outside the strips), so updating them on the strips widened by
+// the stencil radius (2) gives identical results.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BX *BZ) void k_stress_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    const Cell c = my_cell(g);
+    const int z = c.z, x = c.x, P = g.pitch;
+    if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
+    const size_t i = c.i;
+    const bool pz = in_pml_z(g, z);
+    const bool px = (x < g.nPml || x > g.nx - g.nPml - 1);
+    const bool wz = (z < g.nPml + 2 || z > g.nzc - g.nPml - 3);  // psi needed by stencils centred in the strip
+    const bool wx = (x < g.nPml + 2 || x > g.nx - g.nPml - 3);
+    const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
+    const float l2m = lam + 2.0f * mu;
+    const float ba = md.byc_a[i], bb = md.byc_b[i];
+
+    // sxz
+    const float dvz_dx = -dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
+    const float dvx_dz = -dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
+    float us = dvz_dx * pc.rK_x[x] * ba * g.dt + dvx_dz * pc.rK_z[z] * bb * g.dt;
+    if (px) us += pc.a_x[x] * -dplus(m.dsxz_dx[i - 1], m.dsxz_dx[i], m.dsxz_dx[i + 1], m.dsxz_dx[i + 2], g.rdx);
+    if (pz) us += pc.a_z[z] * -dplus(m.dsxz_dz[i - P], m.dsxz_dz[i], m.dsxz_dz[i + P], m.dsxz_dz[i + 2 * P], g.rdz);
+    const float sxz = f.sxz[i] + us;
+    f.sxz[i] = sxz;
+    if (wx) m.dvz_dx[i] = pc.b_xh[x] * m.dvz_dx[i] + sxz * amu * g.dt;
+    if (wz) m.dvx_dz[i] = pc.b_zh[z] * m.dvx_dz[i] + sxz * amu * g.dt;
+
+    // sxx, szz
+    const float dvx_dx = -dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
+    const float dvz_dz = -dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
+    float ux = bb * dvx_dx * pc.rK_xh[x] * g.dt;
+    float uz = ba * dvz_dz * pc.rK_zh[z] * g.dt;
+    if (px) ux += pc.a_xh[x] * -dminus(m.dsxx_dx[i - 2], m.dsxx_dx[i - 1], m.dsxx_dx[i], m.dsxx_dx[i + 1], g.rdx);
+    if (pz) uz += pc.a_zh[z] * -dminus(m.dszz_dz[i - 2 * P], m.dszz_dz[i - P], m.dszz_dz[i], m.dszz_dz[i + P], g.rdz);
+    const float sxx = f.sxx[i] + ux;
+    const float szz = f.szz[i] + uz;
+    f.sxx[i] = sxx;
+    f.szz[i] = szz;
+    if (wx) m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
+    if (wz) m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// receivers.  Seismograms are kept time-major on the device: d[comp][it][rec]  (coalesced for a
+// horizontal fibre); they are transposed to the reference's [rec][it] files only on export.
+// comps bit mask: 1 pressure, 2 vx, 4 vz, 8 ett.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_record(Grid g, Fields f, int nrec, const int *__restrict__ rec_idx /* z*pitch+x */,
+                         float *__restrict__ d_pr, float *__restrict__ d_vx, float *__restrict__ d_vz,
+                         float *__restrict__ d_ett, int comps) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const int i = rec_idx[r];
+    if (comps & 1) d_pr[r] = f.szz[i] + f.sxx[i];
+    const float vx = f.vx[i];
+    if (comps & 2) d_vx[r] = vx;
+    if (comps & 4) d_vz[r] = f.vz[i];
+    if (comps & 8) d_ett[r] = vx - f.vx[i - 1];  // not divided by dx (utilities.cu:600-601)
+}
+
+// res_injection_exx: vx_adj(z,x) += r ; vx_adj(z,x-1) -= r.  Adjacent channels share cells, so the
+// two statements are applied through float atomics (the reference's plain +=/-= is racy there,
+// utilities.cu:613-614).  Atomic order only permutes two adds per cell.
+__global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, const float *__restrict__ res_t) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const int i = rec_idx[r];
+    const float v = res_t[r];
+    atomicAdd(&adj.vx[i], v);
+    atomicAdd(&adj.vx[i - 1], -v);
+}
+
+// residual r = obs - syn (time sample 0 forced to 0) and sum r^2, all time-major [it][rec].
+// One double partial per block -> atomicAdd(double).
+__global__ void k_residual(const float *__restrict__ obs, const float *__restrict__ syn, float *__restrict__ res,
+                           int nrec, long long n, double *__restrict__ sumsq) {
+    double s = 0.0;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        float r = (k < nrec) ? 0.0f : (obs[k] - syn[k]);  // first time sample: utilities.cu:159-163
+        res[k] = r;
+        s += (double)r * (double)r;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += part[k];
+        atomicAdd(sumsq, t);
+    }
+}
+
+// [rows][cols] -> [cols][rows] through a padded LDS tile (used for seismogram import/export).
+__global__ void k_transpose(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        int r = r0 + k;
+        if (r < rows && c < cols) tile[k][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    int orow0 = blockIdx.x * 32, oc = blockIdx.y * 32 + threadIdx.x;
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        int orow = orow0 + k;
+        if (orow < cols && oc < rows) out[(size_t)orow * rows + oc] = tile[threadIdx.x][k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// media preparation: boundary arrays (nz, nx) dense [MPa] -> internal pitched arrays [Pa] + averages
+// ---------------------------------------------------------------------------------------------
+__global__ void k_model_prep(Grid g, const float *__restrict__ Lam_in, const float *__restrict__ Mu_in,
+                             const float *__restrict__ Den_in, float *__restrict__ lam, float *__restrict__ mu,
+                             float *__restrict__ ave_mu, float *__restrict__ byc_a, float *__restrict__ byc_b,
+                             unsigned int *__restrict__ cp2_max_bits) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = blockIdx.y * blockDim.y + threadIdx.y;
+    float cp2 = 0.0f;
+    if (x < g.nx && z < g.nz) {
+        const size_t si = (size_t)z * g.nx + x;
+        const float L = (float)((double)Lam_in[si] * 1e6);  // libCUFD.cu:73-74
+        const float M = (float)((double)Mu_in[si] * 1e6);
+        const float D = Den_in[si];
+        cp2 = (float)(((double)L + 2.0 * (double)M) / (double)D);  // velInit, utilities.cu:119-120 (squared)
+        if (z < g.nzc) {
+            const size_t i = (size_t)z * g.pitch + x;
+            lam[i] = L;
+            mu[i] = M;
+            float am = 0.0f, ba = 1.0f / 1000.0f, bb = 1.0f / 1000.0f;  // Model.cu:67,72-73
+            // averages exist on [2, n-3] of the FULL padded grid (utilities.cu:129,146); rows >= nzc are
+            // never read by any kernel.
+            if (z >= 2 && z <= g.nz - 3 && x >= 2 && x <= g.nx - 3) {
+                const double a = M;
+                const double b = (double)Mu_in[si + g.nx] * 1e6;
+                const double c = (double)Mu_in[si + 1] * 1e6;
+                const double d = (double)Mu_in[si + g.nx + 1] * 1e6;
+                const float bf = (float)b, cf = (float)c, df = (float)d;
+                if (!(M == 0.0f || bf == 0.0f || cf == 0.0f || df == 0.0f))
+                    am = (float)(4.0 / (1.0 / a + 1.0 / (double)bf + 1.0 / (double)cf + 1.0 / (double)df));
+                ba = (float)(2.0 / (double)(Den_in[si + g.nx] + D));
+                bb = (float)(2.0 / (double)(Den_in[si + 1] + D));
+            }
+            ave_mu[i] = am;
+            byc_a[i] = ba;
+            byc_b[i] = bb;
+        }
+    }
+    // max over the whole padded grid for the Courant guard (utilities.cu:225-232).  Cp^2 > 0, so the
+    // float bit pattern orders like the value.
+    for (int off = 32; off > 0; off >>= 1) cp2 = fmaxf(cp2, __shfl_down(cp2, off, 64));
+    if ((threadIdx.y * blockDim.x + threadIdx.x) % 64 == 0 && cp2 > 0.0f) atomicMax(cp2_max_bits, __float_as_uint(cp2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient finalisation (once per call): gather form of the reference's sprays, written straight
+// into the boundary layout (nz, nx) dense -- rows >= nzc are zero.
+//   el_stress.cu:108-123 :  gLam = MEGA*acc.lam ; gMu = MEGA*acc.mu + sum_p S(p)/mu(z,x)^2 over the
+//       staggered points p in {(z,x),(z-1,x),(z,x-1),(z-1,x-1)} that sprayed onto (z,x)
+//   el_velocity.cu:101-110: gDen = A(z,x)+B(z,x)+A(z-1,x)+B(z,x-1), A = acc.a*(-byc_a^2/2), ...
+// including the reference's edge tests (the x+1 spray is unconditional).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xz_weight(const Grid &g, const Media &md, const ImgAcc &acc, int pz, int px) {
+    if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
+    const size_t p = (size_t)pz * g.pitch + px;
+    const float am = md.ave_mu[p];
+    if (am == 0.0f) return 0.0f;
+    const double h = 1.0 / (double)md.mu[p] + 1.0 / (double)md.mu[p + g.pitch] + 1.0 / (double)md.mu[p + 1] +
+                     1.0 / (double)md.mu[p + g.pitch + 1];
+    return (float)((double)(acc.xz[p] * am) / h * 1e6);
+}
+
+__global__ void k_finalize_gradients(Grid g, Media md, ImgAcc acc, float *__restrict__ gLam, float *__restrict__ gMu,
+                                     float *__restrict__ gDen) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.nx || z >= g.nz) return;
+    const size_t o = (size_t)z * g.nx + x;
+    float gl = 0.0f, gm = 0.0f, gd = 0.0f;
+    // targets can lie one column right of the interior (always-true x test of the reference)
+    if (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax + 1) {
+        const size_t i = (size_t)z * g.pitch + x;
+        const bool inside = (x <= g.xmax);
+        if (inside) {
+            gl = (float)((double)acc.lam[i] * 1e6);
+            gm = (float)((double)acc.mu[i] * 1e6);
+        }
+        const double rmu2 = 1.0 / ((double)md.mu[i] * (double)md.mu[i]);
+        float s;
+        s = xz_weight(g, md, acc, z, x);          gm += (float)(rmu2 * (double)s);   // own corner
+        s = xz_weight(g, md, acc, z - 1, x);      gm += (float)(rmu2 * (double)s);   // sprayed down (z+1<=zmax holds: target z<=zmax)
+        s = xz_weight(g, md, acc, z, x - 1);      gm += (float)(rmu2 * (double)s);   // sprayed right, unconditional
+        if (inside) { s = xz_weight(g, md, acc, z - 1, x - 1); gm += (float)(rmu2 * (double)s); }
+        // density
+        auto A = [&](int pz, int px) -> float {
+            if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
+            const size_t p = (size_t)pz * g.pitch + px;
+            const double b = md.byc_a[p];
+            return (float)((double)acc.a[p] * (-(b * b) / 2.0));
+        };
+        auto B = [&](int pz, int px) -> float {
+            if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
+            const size_t p = (size_t)pz * g.pitch + px;
+            const double b = md.byc_b[p];
+            return (float)((double)acc.b[p] * (-(b * b) / 2.0));
+        };
+        gd = A(z, x) + B(z, x) + A(z - 1, x) + B(z, x - 1);
+    }
+    gLam[o] = gl;
+    gMu[o] = gm;
+    gDen[o] = gd;
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+static inline dim3 field_grid(const Grid &g) { return dim3((g.nx + BX - 1) / BX, (g.nzc + BZ - 1) / BZ); }
+
+void launch_stress_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
+                       int z_src, int x_src, float src_amp) {
+    Fields none{};
+    ImgAcc na{};
+    if (frame_t)
+        hipLaunchKernelGGL((k_stress<true, true>), field_grid(g), dim3(BX * BZ), 0, st, g, f, m, md, pc, frame_t, z_src,
+                           x_src, src_amp, none, na);
+    else
+        hipLaunchKernelGGL((k_stress<true, false>), field_grid(g), dim3(BX * BZ), 0, st, g, f, m, md, pc, frame_t, z_src,
+                           x_src, src_amp, none, na);
+}
+
+void launch_velocity_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    Fields none{};
+    ImgAcc na{};
+    hipLaunchKernelGGL((k_velocity<true>), field_grid(g), dim3(BX * BZ), 0, st, g, f, m, md, pc, (const float *)nullptr,
+                       -1, -1, 0.0f, (float *)nullptr, none, na);
+}
+
+void launch_velocity_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
+                         int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
+    PmlMem nm{};
+    hipLaunchKernelGGL((k_velocity<false>), field_grid(g), dim3(BX * BZ), 0, st, g, f, nm, md, pc, frame_t, z_src, x_src,
+                       src_rxz, stf_grad_it, adj, acc);
+}
+
+void launch_stress_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, float *frame_t, int z_src,
+                       int x_src, float src_amp, Fields adj, ImgAcc acc) {
+    PmlMem nm{};
+    hipLaunchKernelGGL((k_stress<false, false>), field_grid(g), dim3(BX * BZ), 0, st, g, f, nm, md, pc, frame_t, z_src,
+                       x_src, src_amp, adj, acc);
+}
+
+void launch_velocity_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc) {
+    hipLaunchKernelGGL(k_velocity_adj, field_grid(g), dim3(BX * BZ), 0, st, g, adj, m, md, pc);
+}
+
+void launch_stress_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc) {
+    hipLaunchKernelGGL(k_stress_adj, field_grid(g), dim3(BX * BZ), 0, st, g, adj, m, md, pc);
+}
+
+void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
+                   float *d_vz, float *d_ett, int comps) {
+    if (nrec <= 0) return;
+    hipLaunchKernelGGL(k_record, dim3((nrec + 255) / 256), dim3(256), 0, st, g, f, nrec, rec_idx, d_pr, d_vx, d_vz, d_ett,
+                       comps);
+}
+
+void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t) {
+    if (nrec <= 0) return;
+    hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t);
+}
+
+void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
+                     double *sumsq) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, obs, syn, res, nrec, n, sumsq);
+}
+
+void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, out, rows, cols);
+}
+
+void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const float *Mu_in, const float *Den_in,
+                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, unsigned int *cp2_max_bits) {
+    hipLaunchKernelGGL(k_model_prep, dim3((g.nx + 63) / 64, (g.nz + 3) / 4), dim3(64, 4), 0, st, g, Lam_in, Mu_in, Den_in,
+                       lam, mu, ave_mu, byc_a, byc_b, cp2_max_bits);
+}
+
+void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
+                               float *gDen) {
+    hipLaunchKernelGGL(k_finalize_gradients, dim3((g.nx + 63) / 64, (g.nz + 3) / 4), dim3(64, 4), 0, st, g, md, acc, gLam,
+                       gMu, gDen);
+}
+
+}  // namespace sepfwi

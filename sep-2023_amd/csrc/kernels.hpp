@@ -1,0 +1,29 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fwi_types.hpp"
+
+namespace sepfwi {
+
+void launch_stress_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
+                       int z_src, int x_src, float src_amp);
+void launch_velocity_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc);
+void launch_velocity_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
+                         int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc);
+void launch_stress_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, float *frame_t, int z_src,
+                       int x_src, float src_amp, Fields adj, ImgAcc acc);
+void launch_velocity_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
+void launch_stress_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
+void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
+                   float *d_vz, float *d_ett, int comps);
+void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t);
+void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
+                     double *sumsq);
+void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);
+void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const float *Mu_in, const float *Den_in,
+                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, unsigned int *cp2_max_bits);
+void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
+                               float *gDen);
+
+}  // namespace sepfwi

@@ -1,0 +1,454 @@
+// session.cpp -- persistent per-(parameter file, GPU) propagation session and the cufd driver.
+//
+// Replaces the per-call host driver of the reference, Src/libCUFD.cu:32-820 (set-up :39-165, shot loop
+// :170-708, gradient read-back :710-724, seismogram files :755-769) and the classes it instantiates on
+// every call: Model (Src/Model.cu), Cpml (Src/Cpml.cu), Bnd (Src/Boundary.cu), Src_Rec (Src/Src_Rec.cu).
+// Differences by design: device state is allocated once and kept; observed data are cached
+// in HBM (time-major) instead of being re-read from four files per shot per call; only the axial-strain
+// (ett) residual -- the only one that enters misfit and adjoint source (libCUFD.cu:427,607) -- is formed.
+#include "session.hpp"
+
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+
+#include "kernels.hpp"
+
+namespace sepfwi {
+
+#define HIP_OK(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            throw HipError(std::string("HIP error '") + hipGetErrorString(e_) + "' at " + __FILE__ + ":" +    \
+                           std::to_string(__LINE__) + " in " #call);                                          \
+    } while (0)
+
+static const char *kComp[4] = {"pr", "vx", "vz", "ett"};  // libCUFD.cu:216-223,755-769
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+static bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear: plain host memory is reported as an error on some ROCm versions
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static std::string shot_file(const Params &p, int comp, int id) {
+    return p.data_dir_name + "/Shot_" + kComp[comp] + std::to_string(id) + ".bin";
+}
+
+template <class T>
+T *Session::dalloc(size_t n) {
+    void *p = nullptr;
+    HIP_OK(hipMalloc(&p, n * sizeof(T)));
+    allocs_.push_back(p);
+    device_bytes_ += (long long)(n * sizeof(T));
+    return (T *)p;
+}
+
+Session::Session(const std::string &para_fname, int gpu_id, const std::string &para_text,
+                 const std::string &survey_text, const Params &par, const Survey &survey)
+    : para_fname_(para_fname), gpu_id_(gpu_id), para_text_(para_text), survey_text_(survey_text), par_(par),
+      survey_(survey) {
+    HIP_OK(hipSetDevice(gpu_id_));
+    HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    for (auto &e : ev_) HIP_OK(hipEventCreate(&e));
+
+    Grid &g = g_;
+    g.nz = par.nz;
+    g.nx = par.nx;
+    g.nzc = par.nz - par.nPad;
+    g.pitch = ((par.nx + 63) / 64) * 64;
+    g.nPml = par.nPml;
+    g.zmax = g.nzc - 1 - par.nPml;
+    g.xmax = par.nx - 1 - par.nPml;
+    g.nSteps = par.nSteps;
+    g.dt = par.dt;
+    g.dz = par.dz;
+    g.dx = par.dx;
+    g.rdz = 1.0f / par.dz;
+    g.rdx = 1.0f / par.dx;
+    g.nzBnd = g.nzc - 2 * par.nPml + 4;  // Boundary.cu:17-18
+    g.nxBnd = par.nx - 2 * par.nPml + 4;
+    g.frame_len = 10 * g.nxBnd + 10 * (g.nzBnd - 10);
+
+    // ---- device arrays ----
+    const size_t n = (size_t)(g.nzc + 4) * (size_t)g.pitch;  // 4 spare rows
+    cells_ = n;
+    // [5 fields | 8 pml memories | 5 adjoint fields] contiguous so one memset clears a group
+    state_ = dalloc<float>(18 * n);
+    float *s = state_;
+    fld_ = Fields{s, s + n, s + 2 * n, s + 3 * n, s + 4 * n};
+    mem_ = PmlMem{s + 5 * n, s + 6 * n, s + 7 * n, s + 8 * n, s + 9 * n, s + 10 * n, s + 11 * n, s + 12 * n};
+    adj_ = Fields{s + 13 * n, s + 14 * n, s + 15 * n, s + 16 * n, s + 17 * n};
+    media_ = dalloc<float>(5 * n);
+    HIP_OK(hipMemset(media_, 0, 5 * n * sizeof(float)));
+    md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n};
+    acc_buf_ = dalloc<float>(5 * n);
+    acc_ = ImgAcc{acc_buf_, acc_buf_ + n, acc_buf_ + 2 * n, acc_buf_ + 3 * n, acc_buf_ + 4 * n};
+    const size_t dense = (size_t)par.nz * (size_t)par.nx;
+    in_stage_ = dalloc<float>(3 * dense);
+    grad_stage_ = dalloc<float>(3 * dense);
+    scal_ = dalloc<double>(4);
+    cp2_bits_ = dalloc<unsigned int>(4);
+    stf_grad_ = dalloc<float>((size_t)par.nSteps);
+
+    // ---- C-PML profiles (host) -> device, with 1/K precomputed ----
+    {
+        const int nzc = g.nzc, nx = g.nx;
+        std::vector<float> K(std::max(nzc, nx)), a(K.size()), b(K.size()), Kh(K.size()), ah(K.size()), bh(K.size());
+        std::vector<float> hz(6 * (size_t)nzc), hx(6 * (size_t)nx);
+        cpml_profiles(K.data(), a.data(), b.data(), Kh.data(), ah.data(), bh.data(), nzc, par.nPml, par.dz, par.f0, par.dt);
+        for (int i = 0; i < nzc; i++) {
+            hz[i] = a[i]; hz[nzc + i] = b[i]; hz[2 * nzc + i] = 1.0f / K[i];
+            hz[3 * nzc + i] = ah[i]; hz[4 * nzc + i] = bh[i]; hz[5 * nzc + i] = 1.0f / Kh[i];
+        }
+        cpml_profiles(K.data(), a.data(), b.data(), Kh.data(), ah.data(), bh.data(), nx, par.nPml, par.dx, par.f0, par.dt);
+        for (int i = 0; i < nx; i++) {
+            hx[i] = a[i]; hx[nx + i] = b[i]; hx[2 * nx + i] = 1.0f / K[i];
+            hx[3 * nx + i] = ah[i]; hx[4 * nx + i] = bh[i]; hx[5 * nx + i] = 1.0f / Kh[i];
+        }
+        float *dz_ = dalloc<float>(hz.size()), *dx_ = dalloc<float>(hx.size());
+        HIP_OK(hipMemcpy(dz_, hz.data(), hz.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dx_, hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice));
+        pc_ = PmlCoef{dz_, dz_ + nzc, dz_ + 2 * nzc, dz_ + 3 * nzc, dz_ + 4 * nzc, dz_ + 5 * nzc,
+                      dx_, dx_ + nx,  dx_ + 2 * nx,  dx_ + 3 * nx,  dx_ + 4 * nx,  dx_ + 5 * nx};
+    }
+
+    // ---- receivers: flat cell index per shot ----
+    {
+        const int ns = (int)survey_.shots.size();
+        rec_off_.assign(ns + 1, 0);
+        for (int i = 0; i < ns; i++) rec_off_[i + 1] = rec_off_[i] + (survey_.shots[i].present ? survey_.shots[i].nrec : 0);
+        std::vector<int> idx((size_t)rec_off_[ns] + 1);
+        for (int i = 0; i < ns; i++) {
+            const Shot &sh = survey_.shots[i];
+            if (!sh.present) continue;
+            if (sh.z_src < 2 || sh.z_src > g.nzc - 3 || sh.x_src < 2 || sh.x_src > g.nx - 3)
+                throw std::runtime_error("survey: source of shot " + std::to_string(i) + " lies outside the computed grid");
+            for (int r = 0; r < sh.nrec; r++) {
+                if (sh.z_rec[r] < 0 || sh.z_rec[r] >= g.nzc || sh.x_rec[r] < 1 || sh.x_rec[r] >= g.nx)
+                    throw std::runtime_error("survey: receiver " + std::to_string(r) + " of shot " + std::to_string(i) +
+                                             " lies outside the grid");
+                idx[(size_t)rec_off_[i] + r] = sh.z_rec[r] * g.pitch + sh.x_rec[r];
+            }
+        }
+        rec_idx_ = dalloc<int>(idx.size());
+        HIP_OK(hipMemcpy(rec_idx_, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    const size_t dlen = (size_t)std::max(1, survey_.max_nrec) * (size_t)par.nSteps;
+    data_len_ = dlen;
+    syn_ = dalloc<float>(4 * dlen);  // time-major pr, vx, vz, ett
+    res_ = dalloc<float>(dlen);
+    xpose_ = dalloc<float>(dlen);
+    HIP_OK(hipHostMalloc((void **)&h_io_, dlen * sizeof(float), hipHostMallocDefault));
+}
+
+Session::~Session() {
+    (void)hipSetDevice(gpu_id_);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : obs_) (void)hipFree(kv.second.d_ett);
+    for (void *p : allocs_) (void)hipFree(p);
+    if (frame_) (void)hipFree(frame_);
+    if (h_io_) (void)hipHostFree(h_io_);
+    for (auto &e : ev_) (void)hipEventDestroy(e);
+    if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void Session::drop_observed() {
+    for (auto &kv : obs_) {
+        (void)hipFree(kv.second.d_ett);
+        device_bytes_ -= (long long)kv.second.bytes;
+    }
+    obs_.clear();
+}
+
+// Observed axial-strain gather of one shot, time-major in HBM; (re)loaded when the file changed.
+const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
+    const std::string fn = shot_file(par_, 3, shot_id);
+    struct stat sb;
+    if (stat(fn.c_str(), &sb) != 0) throw IoError("cannot read observed data '" + fn + "'");  // utilities.cu:12-16
+    const size_t want = (size_t)nrec * (size_t)par_.nSteps * sizeof(float);
+    if ((size_t)sb.st_size < want) throw IoError("observed data '" + fn + "' is shorter than nrec*nSteps floats");
+    auto it = obs_.find(shot_id);
+    if (it != obs_.end() && it->second.mtime_ns == (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec &&
+        it->second.size == (long long)sb.st_size && it->second.bytes == want)
+        return it->second.d_ett;
+    FILE *fp = fopen(fn.c_str(), "rb");
+    if (!fp) throw IoError("cannot read observed data '" + fn + "'");
+    HIP_OK(hipStreamSynchronize(st));  // h_io_ / xpose_ may still be in use
+    size_t got = fread(h_io_, 1, want, fp);
+    fclose(fp);
+    if (got != want) throw IoError("short read on '" + fn + "'");
+    ObsEntry e;
+    if (it != obs_.end()) {
+        e = it->second;
+        if (e.bytes != want) {
+            (void)hipFree(e.d_ett);
+            device_bytes_ -= (long long)e.bytes;
+            e.d_ett = nullptr;
+        }
+    }
+    if (!e.d_ett) {
+        HIP_OK(hipMalloc((void **)&e.d_ett, want));
+        device_bytes_ += (long long)want;
+    }
+    e.bytes = want;
+    e.size = (long long)sb.st_size;
+    e.mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec;
+    HIP_OK(hipMemcpyAsync(xpose_, h_io_, want, hipMemcpyHostToDevice, st));
+    launch_transpose(st, xpose_, e.d_ett, nrec, par_.nSteps);  // [rec][it] -> [it][rec]
+    HIP_OK(hipStreamSynchronize(st));
+    obs_[shot_id] = e;
+    return e.d_ett;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the cufd call
+// ------------------------------------------------------------------------------------------------
+void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf,
+                  const float *Lambda, const float *Mu, const float *Den, const float *stf, int calc_id,
+                  int group_size, const int *shot_ids, hipStream_t ext_stream, bool async) {
+    std::lock_guard<std::mutex> lock(mu_);
+    const auto t_begin = std::chrono::steady_clock::now();
+    HIP_OK(hipSetDevice(gpu_id_));
+    hipStream_t st = ext_stream ? ext_stream : own_stream_;
+    const Grid &g = g_;
+    const bool if_res = (calc_id == 0 || calc_id == 1);  // Parameter.cpp:125-137
+    const bool withAdj = (calc_id == 1);
+    const int nSteps = par_.nSteps;
+    const size_t n = cells_;
+    const size_t dense = (size_t)par_.nz * (size_t)par_.nx;
+    launches_ = 0;
+
+    for (int i = 0; i < group_size; i++) {
+        const int id = shot_ids[i];
+        if (id < 0 || id >= (int)survey_.shots.size() || !survey_.shots[id].present)
+            throw std::invalid_argument("shot id " + std::to_string(id) + " is not in the survey file");
+    }
+
+    // ---- media: boundary arrays -> internal layout, averages, Courant guard ----
+    const float *dL = Lambda, *dM = Mu, *dD = Den;
+    if (!is_device_ptr(Lambda)) { HIP_OK(hipMemcpyAsync(in_stage_, Lambda, dense * sizeof(float), hipMemcpyDefault, st)); dL = in_stage_; }
+    if (!is_device_ptr(Mu)) { HIP_OK(hipMemcpyAsync(in_stage_ + dense, Mu, dense * sizeof(float), hipMemcpyDefault, st)); dM = in_stage_ + dense; }
+    if (!is_device_ptr(Den)) { HIP_OK(hipMemcpyAsync(in_stage_ + 2 * dense, Den, dense * sizeof(float), hipMemcpyDefault, st)); dD = in_stage_ + 2 * dense; }
+    HIP_OK(hipMemsetAsync(cp2_bits_, 0, sizeof(unsigned int), st));
+    launch_model_prep(st, g, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, cp2_bits_);
+    launches_++;
+    {
+        unsigned int bits = 0;
+        HIP_OK(hipMemcpyAsync(&bits, cp2_bits_, sizeof(bits), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        float cp2;
+        std::memcpy(&cp2, &bits, sizeof(cp2));
+        const float vmax = (float)std::sqrt((double)cp2);
+        const float dh_min = (par_.dz < par_.dx) ? par_.dz : par_.dx;
+        const float courant = (float)((double)(vmax * par_.dt * sqrtf(2.0f)) * (1.0 / 24.0 + 9.0 / 8.0) / (double)dh_min);
+        if (!(courant <= 1.0f)) throw CourantError("Courant number " + std::to_string(courant) + " > 1 (vmax " + std::to_string(vmax) + " m/s)");
+    }
+
+    // ---- boundary-saving storage (Boundary.cu:29-41), allocated on first gradient call ----
+    if (withAdj && !frame_) {
+        const size_t fb = (size_t)nSteps * 5 * (size_t)g.frame_len * sizeof(float);
+        HIP_OK(hipMalloc((void **)&frame_, fb));
+        device_bytes_ += (long long)fb;
+    }
+    if (withAdj) HIP_OK(hipMemsetAsync(acc_buf_, 0, 5 * n * sizeof(float), st));  // Model.cu:68-71
+    if (if_res) HIP_OK(hipMemsetAsync(scal_, 0, 4 * sizeof(double), st));
+
+    // ---- source traces on the host: row shot_ids[i] of stf, tapered (Src_Rec.cu:130-137) ----
+    std::vector<float> stf_rows((size_t)group_size * nSteps);
+    for (int i = 0; i < group_size; i++) {
+        HIP_OK(hipMemcpy(stf_rows.data() + (size_t)i * nSteps, stf + (size_t)shot_ids[i] * nSteps, nSteps * sizeof(float),
+                         hipMemcpyDefault));
+        stf_taper(stf_rows.data() + (size_t)i * nSteps, nSteps, par_.dt, 0.001f);
+    }
+    const float src_scale = (float)std::pow(1500.0, 2);  // utilities.cu:531
+
+    fwd_ms_ = bwd_ms_ = 0.0;
+    fwd_steps_ = bwd_steps_ = 0;
+    std::vector<float> h_gstf;
+    if (withAdj) h_gstf.resize(nSteps);
+
+    for (int is = 0; is < group_size; is++) {
+        const int id = shot_ids[is];
+        const Shot &sh = survey_.shots[id];
+        const int nrec = sh.nrec;
+        const int *rec = rec_idx_ + rec_off_[id];
+        const float *stf_s = stf_rows.data() + (size_t)is * nSteps;
+        const float *d_obs = if_res ? observed_ett(id, nrec, st) : nullptr;
+        const int comps = if_res ? 8 : 15;
+        float *d_pr = syn_, *d_vx = syn_ + data_len_, *d_vz = syn_ + 2 * data_len_, *d_ett = syn_ + 3 * data_len_;
+
+        // zero the 5 fields + 8 memory variables (libCUFD.cu:175-194); data column 0 stays 0 (:205-209)
+        HIP_OK(hipMemsetAsync(state_, 0, 13 * n * sizeof(float), st));
+        if (comps & 1) HIP_OK(hipMemsetAsync(d_pr, 0, (size_t)nrec * sizeof(float), st));
+        if (comps & 2) HIP_OK(hipMemsetAsync(d_vx, 0, (size_t)nrec * sizeof(float), st));
+        if (comps & 4) HIP_OK(hipMemsetAsync(d_vz, 0, (size_t)nrec * sizeof(float), st));
+        HIP_OK(hipMemsetAsync(d_ett, 0, (size_t)nrec * sizeof(float), st));
+
+        // ---------------- forward time loop, libCUFD.cu:268-332 ----------------
+        HIP_OK(hipEventRecord(ev_[0], st));
+        for (int it = 0; it <= nSteps - 2; it++) {
+            float *frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
+            const float amp = src_scale * stf_s[it] * par_.dt;
+            launch_stress_fwd(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp);
+            launch_velocity_fwd(st, g, fld_, mem_, md_, pc_);
+            const size_t col = (size_t)(it + 1) * nrec;
+            launch_record(st, g, fld_, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
+            launches_ += 3;
+        }
+        HIP_OK(hipEventRecord(ev_[1], st));
+        fwd_steps_ += nSteps - 1;
+
+        if (!if_res) {
+            // observe: export the four gathers as [nrec][nSteps] files (libCUFD.cu:755-769)
+            for (int c = 0; c < 4; c++) {
+                launch_transpose(st, syn_ + (size_t)c * data_len_, xpose_, nSteps, nrec);  // [it][rec] -> [rec][it]
+                HIP_OK(hipMemcpyAsync(h_io_, xpose_, (size_t)nrec * nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                const std::string fn = shot_file(par_, c, id);
+                FILE *fp = fopen(fn.c_str(), "wb");
+                if (!fp) throw IoError("cannot write '" + fn + "'");  // utilities.cu:22-31
+                size_t w = fwrite(h_io_, sizeof(float), (size_t)nrec * nSteps, fp);
+                fclose(fp);
+                if (w != (size_t)nrec * nSteps) throw IoError("short write on '" + fn + "'");
+            }
+            auto oit = obs_.find(id);  // stale cache entry for this shot: drop, the file just changed
+            if (oit != obs_.end()) {
+                (void)hipFree(oit->second.d_ett);
+                device_bytes_ -= (long long)oit->second.bytes;
+                obs_.erase(oit);
+            }
+        } else {
+            // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
+            launch_residual(st, d_obs, d_ett, res_, nrec, (long long)nrec * nSteps, scal_);
+            launches_++;
+        }
+
+        if (withAdj) {
+            // ---------------- backward, libCUFD.cu:500-675 ----------------
+            // adjoint fields + all eight memory variables restart from zero (:503-515); the two pre-loop
+            // adjoint launches (:520-542) act on all-zero arrays and change nothing.
+            HIP_OK(hipMemsetAsync(state_ + 5 * n, 0, 13 * n * sizeof(float), st));
+            HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
+            HIP_OK(hipEventRecord(ev_[2], st));
+            for (int it = nSteps - 2; it >= 0; it--) {
+                float *frame_t = frame_ + (size_t)it * 5 * (size_t)g.frame_len;
+                const float amp = src_scale * stf_s[it] * par_.dt;
+                launch_velocity_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
+                launch_stress_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
+                launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
+                launch_stress_adj(st, g, adj_, mem_, md_, pc_);
+                launches_ += 5;
+            }
+            HIP_OK(hipEventRecord(ev_[3], st));
+            bwd_steps_ += nSteps - 1;
+            if (grad_stf) {
+                HIP_OK(hipMemcpyAsync(h_gstf.data(), stf_grad_, (size_t)nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                HIP_OK(hipMemcpy(grad_stf + (size_t)is * nSteps, h_gstf.data(), (size_t)nSteps * sizeof(float), hipMemcpyDefault));
+            }
+        }
+        // event times are read shot by shot (cheap: one sync per shot)
+        HIP_OK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+        fwd_ms_ += ms;
+        if (withAdj) {
+            HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
+            bwd_ms_ += ms;
+        }
+    }
+
+    // ---- outputs ----
+    if (withAdj) {
+        const bool devL = is_device_ptr(grad_Lambda), devM = is_device_ptr(grad_Mu), devD = is_device_ptr(grad_Den);
+        float *oL = devL ? grad_Lambda : grad_stage_, *oM = devM ? grad_Mu : grad_stage_ + dense, *oD = devD ? grad_Den : grad_stage_ + 2 * dense;
+        launch_finalize_gradients(st, g, md_, acc_, oL, oM, oD);
+        launches_++;
+        if (!devL) HIP_OK(hipMemcpyAsync(grad_Lambda, oL, dense * sizeof(float), hipMemcpyDefault, st));
+        if (!devM) HIP_OK(hipMemcpyAsync(grad_Mu, oM, dense * sizeof(float), hipMemcpyDefault, st));
+        if (!devD) HIP_OK(hipMemcpyAsync(grad_Den, oD, dense * sizeof(float), hipMemcpyDefault, st));
+    }
+    if (if_res && misfit) {
+        double sumsq = 0.0;
+        HIP_OK(hipMemcpyAsync(&sumsq, scal_, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        const float mf = (float)(0.5 * sumsq);  // libCUFD.cu:776
+        HIP_OK(hipMemcpy(misfit, &mf, sizeof(float), hipMemcpyDefault));
+    }
+    if (!async) HIP_OK(hipStreamSynchronize(st));
+    total_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    last_shots_ = group_size;
+    last_calc_ = calc_id;
+}
+
+void Session::stats(sepfwi_stats *out) const {
+    out->fwd_ms = fwd_ms_;
+    out->bwd_ms = bwd_ms_;
+    out->total_ms = total_ms_;
+    out->n_c = g_.nzc * g_.nx;
+    out->fwd_steps = fwd_steps_;
+    out->bwd_steps = bwd_steps_;
+    out->launches = launches_;
+    out->device_bytes = device_bytes_;
+    // one forward pass = N_c*(nSteps-1); fwd+adj = 3x (forward, reconstruction, adjoint)
+    out->cell_updates = (double)out->n_c * ((double)fwd_steps_ + 2.0 * (double)bwd_steps_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// registry
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_reg_mu;
+static std::map<std::pair<std::string, int>, std::unique_ptr<Session>> g_sessions;
+
+Session &get_session(const std::string &para_fname, int gpu_id) {
+    const std::string ptext = read_first_line(para_fname);
+    Params par = parse_params(ptext);
+    const std::string stext = read_first_line(par.survey_fname);
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    auto key = std::make_pair(para_fname, gpu_id);
+    auto it = g_sessions.find(key);
+    if (it != g_sessions.end() && it->second->matches(ptext, stext)) return *it->second;
+    if (it != g_sessions.end()) g_sessions.erase(it);
+    Survey sv = parse_survey(stext, par.nPml);
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (gpu_id < 0 || gpu_id >= ndev)
+        throw HipError("gpu_id " + std::to_string(gpu_id) + " out of range: " + std::to_string(ndev) + " HIP device(s) visible");
+    g_sessions[key] = std::unique_ptr<Session>(new Session(para_fname, gpu_id, ptext, stext, par, sv));
+    return *g_sessions[key];
+}
+
+Session *find_session(const std::string &para_fname, int gpu_id) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    auto it = g_sessions.find(std::make_pair(para_fname, gpu_id));
+    return it == g_sessions.end() ? nullptr : it->second.get();
+}
+
+void release_all_sessions() {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    g_sessions.clear();
+}
+
+void invalidate_observed_all() {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    for (auto &kv : g_sessions) kv.second->drop_observed();
+}
+
+}  // namespace sepfwi

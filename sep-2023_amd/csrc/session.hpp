@@ -1,0 +1,84 @@
+// session.hpp -- persistent propagation session (see session.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sepfwi.h"
+#include "config.hpp"
+#include "fwi_types.hpp"
+
+namespace sepfwi {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct CourantError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class Session {
+  public:
+    Session(const std::string &para_fname, int gpu_id, const std::string &para_text, const std::string &survey_text,
+            const Params &par, const Survey &survey);
+    ~Session();
+    Session(const Session &) = delete;
+    Session &operator=(const Session &) = delete;
+
+    bool matches(const std::string &ptext, const std::string &stext) const { return ptext == para_text_ && stext == survey_text_; }
+    void run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf, const float *Lambda,
+             const float *Mu, const float *Den, const float *stf, int calc_id, int group_size, const int *shot_ids,
+             hipStream_t ext_stream, bool async);
+    void stats(sepfwi_stats *out) const;
+    void drop_observed();
+    const Params &params() const { return par_; }
+
+  private:
+    template <class T> T *dalloc(size_t n);
+    const float *observed_ett(int shot_id, int nrec, hipStream_t st);
+
+    struct ObsEntry {
+        float *d_ett = nullptr;  // [nSteps][nrec]
+        size_t bytes = 0;
+        long long size = 0, mtime_ns = 0;
+    };
+
+    std::string para_fname_;
+    int gpu_id_;
+    std::string para_text_, survey_text_;
+    Params par_;
+    Survey survey_;
+    Grid g_{};
+    std::mutex mu_;
+    hipStream_t own_stream_ = nullptr;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<void *> allocs_;
+    long long device_bytes_ = 0;
+
+    size_t cells_ = 0, data_len_ = 0;
+    float *state_ = nullptr, *media_ = nullptr, *acc_buf_ = nullptr, *in_stage_ = nullptr, *grad_stage_ = nullptr;
+    float *frame_ = nullptr, *syn_ = nullptr, *res_ = nullptr, *xpose_ = nullptr, *stf_grad_ = nullptr, *h_io_ = nullptr;
+    double *scal_ = nullptr;
+    unsigned int *cp2_bits_ = nullptr;
+    int *rec_idx_ = nullptr;
+    std::vector<int> rec_off_;
+    Fields fld_{}, adj_{};
+    PmlMem mem_{};
+    Media md_{};
+    PmlCoef pc_{};
+    ImgAcc acc_{};
+    std::map<int, ObsEntry> obs_;
+
+    double fwd_ms_ = 0, bwd_ms_ = 0, total_ms_ = 0;
+    long long fwd_steps_ = 0, bwd_steps_ = 0, launches_ = 0;
+    int last_shots_ = 0, last_calc_ = -1;
+};
+
+Session &get_session(const std::string &para_fname, int gpu_id);
+Session *find_session(const std::string &para_fname, int gpu_id);
+void release_all_sessions();
+void invalidate_observed_all();
+
+}  // namespace sepfwi

@@ -1,0 +1,92 @@
+"""Loader / builder of libsepfwi.so, the HIP propagator behind the C ABI of include/sepfwi.h.
+
+There is no CPU fallback: if the library cannot be loaded every operator call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
+CSRC = os.path.join(_ROOT, "csrc")
+LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
+SOURCES = ["kernels.hip", "session.cpp", "config.cpp", "capi.cpp"]
+HEADERS = ["kernels.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+           os.path.join("..", "..", "include", "sepfwi.h")]
+
+_lib = None
+
+
+class Stats(C.Structure):
+    """mirror of struct sepfwi_stats (include/sepfwi.h)"""
+    _fields_ = [("fwd_ms", C.c_double), ("bwd_ms", C.c_double), ("total_ms", C.c_double),
+                ("cell_updates", C.c_double), ("fwd_steps", C.c_longlong), ("bwd_steps", C.c_longlong),
+                ("launches", C.c_longlong), ("device_bytes", C.c_longlong), ("n_c", C.c_int)]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... (cross-compiles without a GPU; ~15 s)."""
+    if not (force or needs_build()):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library (ctypes.CDLL) with argument types declared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: both link libamdhip64.so.7 and must share ONE HIP runtime in the process.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsepfwi.so is not built (%s missing). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback for the propagator." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp, ip = C.c_void_p, C.c_void_p
+    L.sepfwi_last_error.restype = C.c_char_p
+    L.sepfwi_cufd.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, ip, C.c_char_p]
+    L.sepfwi_cufd_stream.argtypes = L.sepfwi_cufd.argtypes + [C.c_void_p, C.c_int]
+    L.sepfwi_cpml_profiles.argtypes = [fp] * 6 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.sepfwi_stf_taper.argtypes = [fp, C.c_int, C.c_float, C.c_float]
+    L.sepfwi_shot_split.argtypes = [C.c_int, C.c_int, ip]
+    L.sepfwi_get_stats.argtypes = [C.c_char_p, C.c_int, C.POINTER(Stats)]
+    L.sepfwi_set_option.argtypes = [C.c_char_p, C.c_int]
+    for f in ("sepfwi_cufd", "sepfwi_cufd_stream", "sepfwi_cpml_profiles", "sepfwi_stf_taper", "sepfwi_shot_split",
+              "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_version", "sepfwi_device_count"):
+        getattr(L, f).restype = C.c_int
+    L.sepfwi_release_all.restype = None
+    L.sepfwi_invalidate_observed.restype = None
+    _lib = L
+    return L
+
+
+EXPORTS = ["sepfwi_last_error", "sepfwi_version", "sepfwi_device_count", "sepfwi_cufd", "sepfwi_cufd_stream",
+           "sepfwi_release_all", "sepfwi_invalidate_observed", "sepfwi_cpml_profiles", "sepfwi_stf_taper",
+           "sepfwi_shot_split", "sepfwi_get_stats", "sepfwi_set_option"]
+
+
+class SepFwiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sepfwi error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc: int):
+    if rc != 0:
+        raise SepFwiError(rc, lib().sepfwi_last_error().decode(errors="replace"))

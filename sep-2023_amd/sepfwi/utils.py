@@ -1,0 +1,90 @@
+"""Host-side helpers that produce the INPUTS of the propagator (unchanged semantics of the reference's
+fwi_utils.py): JSON writers, Ricker source, replicate padding.  Pure numpy / torch."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def nPad_for(nz: int, nPml: int, multiple: int = 32) -> int:
+    """Rows appended below the bottom PML so that nz + 2 nPml + nPad is a multiple of 32
+    (Main-001-FWI-Anomaly-Vp-Vs-Den.py:35; yields 32, not 0, when already a multiple)."""
+    return int(multiple - np.mod(nz + 2 * nPml, multiple))
+
+
+def padding_numpy_array(arr: np.ndarray, npml: int, npad: int) -> np.ndarray:
+    """Edge-replicate a (nz, nx) array to (nz + 2 npml + npad, nx + 2 npml)   (fwi_utils.py:11-27)."""
+    return np.pad(arr, ((npml, npml + npad), (npml, npml)), mode="edge")
+
+
+def padding(cp, cs, den, nz_orig, nx_orig, nz, nx, nPml, nPad):
+    """Bilinear resize to (nz, nx) (identity when sizes agree) then replicate padding; differentiable
+    (fwi_utils.py:31-44)."""
+    out = []
+    for t in (cp, cs, den):
+        t4 = t.view(1, 1, nz_orig, nx_orig)
+        t4 = F.interpolate(t4, size=(nz, nx), mode="bilinear", align_corners=False)
+        t4 = F.pad(t4, pad=(nPml, nPml, nPml, nPml + nPad), mode="replicate")
+        out.append(t4.view(nz + 2 * nPml + nPad, nx + 2 * nPml))
+    return tuple(out)
+
+
+def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir_name,
+            if_win=False, filter_para=None, if_src_update=False, scratch_dir_name="", if_cross_misfit=False):
+    """Write the one-line parameter JSON (schema of fwi_utils.py:46-83; nz, nx are the PADDED sizes)."""
+    para = {"nz": int(nz), "nx": int(nx), "dz": dz, "dx": dx, "nSteps": int(nSteps), "dt": float(dt),
+            "f0": f0, "nPoints_pml": int(nPml), "nPad": int(nPad)}
+    if if_win:
+        para["if_win"] = True
+    if filter_para is not None:
+        para["filter"] = filter_para
+    if if_src_update:
+        para["if_src_update"] = True
+    para["survey_fname"] = survey_fname
+    para["data_dir_name"] = data_dir_name
+    os.makedirs(data_dir_name, exist_ok=True)
+    if if_cross_misfit:
+        para["if_cross_misfit"] = True
+    if scratch_dir_name != "":
+        para["scratch_dir_name"] = scratch_dir_name
+        os.makedirs(scratch_dir_name, exist_ok=True)
+    with open(para_fname, "w") as fp:
+        json.dump(para, fp)
+
+
+def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Src_Weights=None, Src_rxz=None, Rec_rxz=None):
+    """Write the one-line survey JSON: every shot shares the receiver list; indices are UNPADDED grid
+    indices (fwi_utils.py:87-124)."""
+    z_src = np.asarray(z_src).tolist()
+    x_src = np.asarray(x_src).tolist()
+    z_rec = np.asarray(z_rec).tolist()
+    x_rec = np.asarray(x_rec).tolist()
+    survey = {"nShots": len(x_src)}
+    for i in range(len(x_src)):
+        shot = {"z_src": int(z_src[i]), "x_src": int(x_src[i]), "nrec": len(x_rec),
+                "z_rec": [int(v) for v in z_rec], "x_rec": [int(v) for v in x_rec]}
+        if Src_Weights is not None:
+            shot["src_weight"] = Src_Weights[i]
+        if Src_rxz is not None:
+            shot["src_rxz"] = Src_rxz[i]
+        if Rec_rxz is not None:
+            shot["rec_rxz"] = np.asarray(Rec_rxz).tolist()
+        survey["shot%d" % i] = shot
+    with open(survey_fname, "w") as fp:
+        json.dump(survey, fp)
+
+
+def sourceGene(f, nStep, delta_t):
+    """Ricker wavelet, delay 1.2/f, amplitude 1e7, float64 (fwi_utils.py:127-140)."""
+    e = np.pi * np.pi * f * f
+    tau = delta_t * np.arange(nStep) - 1.2 / f
+    return (1.0 - 2.0 * e * tau ** 2) * np.exp(-e * tau ** 2) * 1.0e7
+
+
+def read_shot_gather(data_dir, comp, shot_id, nSteps):
+    """Shot_{pr|vx|vz|ett}{id}.bin -> (nrec, nSteps) float32 (libCUFD.cu:755-769)."""
+    return np.fromfile(os.path.join(data_dir, "Shot_%s%d.bin" % (comp, shot_id)), dtype=np.float32).reshape(-1, nSteps)

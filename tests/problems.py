@@ -1,0 +1,75 @@
+"""Seeded synthetic set-ups shared by the parity tests (inputs only; no reference code)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from sepfwi import utils as ft
+
+
+def smooth_random(rng, shape, lo, hi, passes=8):
+    a = rng.standard_normal(shape)
+    for _ in range(passes):
+        a = 0.25 * (np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1))
+    a = (a - a.min()) / (a.max() - a.min())
+    return lo + (hi - lo) * a
+
+
+def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, dt=1.0e-3, f0=25.0,
+                 hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None):
+    """Writes para/survey JSON under workdir and returns everything a test needs.
+    Models: `true` (with anomalies) and `init` (smooth), both (nz, nx) float32, plus padded versions."""
+    rng = np.random.default_rng(seed)
+    if nPad is None:
+        nPad = ft.nPad_for(nz, nPml)
+    nz_pad, nx_pad = nz + 2 * nPml + nPad, nx + 2 * nPml
+    if hetero:
+        vp0 = smooth_random(rng, (nz, nx), 2600.0, 3800.0)
+        vs0 = vp0 / smooth_random(rng, (nz, nx), 1.65, 1.85)
+        rho0 = smooth_random(rng, (nz, nx), 2100.0, 2600.0)
+    else:
+        vp0 = np.full((nz, nx), 3000.0)
+        vs0 = vp0 / 1.732
+        rho0 = np.full((nz, nx), 2400.0)
+    vp1, vs1, rho1 = vp0.copy(), vs0.copy(), rho0.copy()
+    z0, x0 = nz // 2, nx // 3
+    vp1[z0 - 4:z0 + 4, x0 - 4:x0 + 4] *= 1.05
+    vs1[z0 - 4:z0 + 4, 2 * x0 - 4:2 * x0 + 4] *= 0.95
+    rho1[z0 + 5:z0 + 11, nx // 2 - 4:nx // 2 + 4] *= 1.04
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    true = dict(vp=f32(vp1), vs=f32(vs1), rho=f32(rho1))
+    init = dict(vp=f32(vp0), vs=f32(vs0), rho=f32(rho0))
+
+    os.makedirs(workdir, exist_ok=True)
+    para_fname = os.path.join(workdir, "para_file.json")
+    survey_fname = os.path.join(workdir, "survey_file.json")
+    data_dir = os.path.join(workdir, "Data")
+    ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir)
+    src_x = np.linspace(6, nx - 7, nshots).round().astype(int)
+    src_zs = np.full(nshots, src_z, dtype=int)
+    rec_x = np.arange(4, nx - 4, nrec_stride).astype(int)
+    rec_zs = np.full(rec_x.shape, (nz - 6) if rec_z is None else rec_z, dtype=int)
+    ft.surveyGen(src_zs, src_x, rec_zs, rec_x, survey_fname)
+    stf = ft.sourceGene(f0, nSteps, dt)
+    Stf = torch.tensor(stf, dtype=torch.float32).repeat(nshots, 1)
+    Shot_ids = torch.arange(nshots, dtype=torch.int32)
+    opt = dict(nz=nz, nx=nx, nz_orig=nz, nx_orig=nx, nPml=nPml, nPad=nPad, para_fname=para_fname)
+
+    def padded(m):
+        t = {k: torch.tensor(ft.padding_numpy_array(v, nPml, nPad)) for k, v in m.items()}
+        lam = (t["vp"] ** 2 - 2.0 * t["vs"] ** 2) * t["rho"] / 1e6   # FWI_ops.py:134-135
+        mu = t["vs"] ** 2 * t["rho"] / 1e6
+        return lam.contiguous(), mu.contiguous(), t["rho"].contiguous()
+
+    return dict(para_fname=para_fname, survey_fname=survey_fname, data_dir=data_dir, opt=opt, true=true, init=init,
+                Stf=Stf, Shot_ids=Shot_ids, nrec=int(rec_x.size), nSteps=nSteps, nPml=nPml, nPad=nPad,
+                nz_pad=nz_pad, nx_pad=nx_pad, lame_true=padded(true), lame_init=padded(init),
+                para=json.load(open(para_fname)), survey=json.load(open(survey_fname)))
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    d = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a))
