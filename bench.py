@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path (BASELINE.json: "Gcell-updates/s (fwd+adj),
+2000x1000 grid x 4000 steps; 1/2/4/8 GPUs").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one FWI gradient evaluation (`fwi_ops.backward`: forward + boundary-saving adjoint of ONE
+shot per GPU on the 2000x1000 model, 4000 time steps, plus -- for N > 1 -- the single RCCL all-reduce of
+[gLambda|gMu|gDen|misfit]).  Weak scaling: every rank owns one shot per step.  Inputs (model, source,
+observed data) are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+
+cell-update = one grid cell advanced one time step by one propagator; a fwd+adj shot is
+3 * N_c * (nSteps-1) updates with N_c = (nz+2nPml)*(nx+2nPml).
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "sep-2023_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_UPDATE_FWDADJ = 184.0 / 3.0   # 60 B fwd + 124 B bwd per cell per step = 61.33 B / cell-update
+BYTES_FWD = 60.0
+
+
+def marmousi_style(nz, nx, seed=2023):
+    """SURVEY.md 8(d) C2/C3 synthetic: 1-D gradient Vp 1500->4500 + Gaussian-filtered N(0,1) perturbation
+    (sigma 8 cells, +-10 %), Vs = Vp/1.732, rho = 310 Vp^0.25; initial = Gaussian-smoothed (sigma 40)."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    base = np.linspace(1500.0, 4500.0, nz)[:, None] * np.ones((1, nx))
+    pert = gaussian_filter(rng.standard_normal((nz, nx)), 8.0)
+    pert = 0.1 * pert / np.abs(pert).max()
+    vp = base * (1.0 + pert)
+    vp0 = gaussian_filter(vp, 40.0)
+    mk = lambda v: (v.astype(np.float32), (v / 1.732).astype(np.float32), (310.0 * v ** 0.25).astype(np.float32))
+    return mk(vp), mk(vp0)
+
+
+def setup_problem(workdir, nz, nx, nSteps, n_shots_total, nPml=32, dh=10.0, dt=1.0e-3, f0=10.0):
+    from sepfwi import utils as ft
+    nPad = ft.nPad_for(nz, nPml)
+    nz_pad, nx_pad = nz + 2 * nPml + nPad, nx + 2 * nPml
+    para_fname = os.path.join(workdir, "para_file.json")
+    survey_fname = os.path.join(workdir, "survey_file.json")
+    ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, os.path.join(workdir, "Data"))
+    src_x = (10 + np.round(np.arange(n_shots_total) * (nx - 21) / max(n_shots_total - 1, 1))).astype(int)
+    rec_x = np.arange(10, nx - 10).astype(int)
+    ft.surveyGen(np.full(src_x.shape, 2), src_x, np.full(rec_x.shape, 2), rec_x, survey_fname)
+    true, init = marmousi_style(nz, nx)
+
+    def lame(m):
+        vp, vs, rho = [torch.tensor(ft.padding_numpy_array(a, nPml, nPad)) for a in m]
+        return ((vp ** 2 - 2.0 * vs ** 2) * rho / 1e6).contiguous(), (vs ** 2 * rho / 1e6).contiguous(), rho.contiguous()
+
+    Stf = torch.tensor(ft.sourceGene(f0, nSteps, dt), dtype=torch.float32).repeat(n_shots_total, 1)
+    return dict(para_fname=para_fname, lame_true=lame(true), lame_init=lame(init), Stf=Stf, nPad=nPad, nPml=nPml,
+                nz_pad=nz_pad, nx_pad=nx_pad, n_c=(nz + 2 * nPml) * nx_pad, nrec=int(rec_x.size))
+
+
+def cpu_baseline(nz, nx, seconds=15.0):
+    """The reference's CPU propagator is the Numba solver (DAS_Waveform_Modeling/src/elasticSolver.py);
+    numba cannot travel, so its C restatement (oracle/numba_oracle.c, pinned bit-for-bit to the reference
+    by tests/golden/numba_*.npz) is timed: one shot per host core, like Pool(min(nsrc, cpu_count))
+    (elasticSolver.py:163-166), on the SAME 2000x1000 grid for a bounded number of steps."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    ndamp = 32
+    vp = np.full((nx, nz), 3000.0)
+    vs = vp / 1.732
+    rho = np.full((nx, nz), 2400.0)
+    src = np.array([[nx // 2 * 10.0, nz // 2 * 10.0]])
+    rec = np.array([[nx // 3 * 10.0, nz // 3 * 10.0]])
+
+    def run(nt):
+        t0 = time.perf_counter()
+        O.numba_forward(nx, nz, ndamp, 10.0, 10.0, 1.0e-3, nt, 10.0, vp, vs, rho, src, rec, rec, np.zeros((1, 6)))
+        return time.perf_counter() - t0
+
+    t_probe = run(4)
+    nt = int(max(4, min(400, seconds / max(t_probe / 4.0, 1e-6))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda _: run(nt), range(cores)))
+    el = time.perf_counter() - t0
+    cells = (nx + 2 * ndamp) * (nz + 2 * ndamp)
+    val = cores * cells * nt / el / 1e9
+    return {"value": round(val, 5), "unit": "Gcell-updates/s", "cores": cores, "kind": "port",
+            "sample": "float64 C restatement of elasticSolver.py (velocity+stress = 1 cell-update), %dx%d grid + %d sponge, "
+                      "%d steps, %d shots in parallel (one per core), forward only, %.1f s" % (nx, nz, ndamp, nt, cores, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nz", type=int, default=1000)
+    ap.add_argument("--nx", type=int, default=2000)
+    ap.add_argument("--nsteps", type=int, default=4000, help="time steps per shot")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="fwdadj", choices=["fwdadj", "fwd"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as td
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE under torchrun"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from sepfwi import fwi_ops
+    fwi_ops.device_override = local
+    K, W = args.steps, args.warmup
+    per_rank_shots = max(K, 1)
+    n_total = world * per_rank_shots
+    workdir = tempfile.mkdtemp(prefix="sepfwi_bench_r%d_" % rank)
+    try:
+        pb = setup_problem(workdir, args.nz, args.nx, args.nsteps, n_total)
+        lam_t, mu_t, den_t = [t.to(dev) for t in pb["lame_true"]]
+        lam, mu, den = [t.to(dev) for t in pb["lame_init"]]
+        Stf = pb["Stf"]
+        # shot ids: step s uses [s*world + r for r in ranks] -> every rank exactly one shot per step
+        my_ids = [s * world + rank for s in range(per_rank_shots)]
+        # observed data for my shots (untimed set-up; each rank writes its own files, then caches them in HBM)
+        from sepfwi import dist as _dist
+        _cufd = fwi_ops._cufd
+        _cufd(2, local, lam_t, mu_t, den_t, Stf, torch.tensor(my_ids, dtype=torch.int32), pb["para_fname"])
+        del lam_t, mu_t, den_t
+
+        def step(s):
+            ids = torch.tensor([s * world + r for r in range(world)], dtype=torch.int32)
+            if args.mode == "fwd":
+                return fwi_ops.forward(lam, mu, den, Stf, local, ids[rank:rank + 1], pb["para_fname"])
+            return fwi_ops.backward(lam, mu, den, Stf, world, ids, pb["para_fname"])
+
+        for w in range(W):
+            step(w % per_rank_shots)
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fwd_ms = bwd_ms = 0.0
+        for s in range(K):
+            step(s)
+            st = fwi_ops.stats(pb["para_fname"], local)
+            fwd_ms += st["fwd_ms"]
+            bwd_ms += st["bwd_ms"]
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el = float(t.item())
+
+        passes = 3 if args.mode == "fwdadj" else 1
+        updates_per_shot = passes * pb["n_c"] * (args.nsteps - 1)
+        value = world * K * updates_per_shot / el / 1e9
+        if rank == 0:
+            # roofline of the dominant kernel group, measured live with HIP events on the session stream
+            # (sepfwi_stats.fwd_ms / bwd_ms): algorithmic bytes per time step / measured time per time step.
+            nst = K * (args.nsteps - 1)
+            if args.mode == "fwdadj":
+                per_step_us = bwd_ms * 1e3 / nst
+                ach = pb["n_c"] * 124.0 / (per_step_us * 1e-6) / 1e9
+                kern = "backward time step (k_velocity<REV>+k_stress<REV>+k_velocity_adj+k_inject+k_stress_adj)"
+            else:
+                per_step_us = fwd_ms * 1e3 / nst
+                ach = pb["n_c"] * BYTES_FWD / (per_step_us * 1e-6) / 1e9
+                kern = "forward time step (k_stress<FWD>+k_velocity<FWD>+k_record)"
+            out = {
+                "metric": "Gcell-updates/s (fwd+adj), 2000x1000 grid x 4000 steps" if args.mode == "fwdadj" else "Gcell-updates/s (fwd)",
+                "value": round(value, 4), "unit": "Gcell-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": round(el * 1e3 / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[2] shape: %dx%d model (padded %dx%d), %d time steps, %d DAS channels, "
+                                       "1 shot per GPU per step, %s" % (args.nx, args.nz, pb["nx_pad"], pb["nz_pad"], args.nsteps,
+                                                                        pb["nrec"], "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
+                           "cell_updates_per_shot": updates_per_shot, "parallelism": "shots x%d" % world},
+                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kern,
+                             "avg_us": round(per_step_us, 2),
+                             "whole_job_frac": round(value * (BYTES_PER_UPDATE_FWDADJ if args.mode == "fwdadj" else BYTES_FWD) / world / HBM_PEAK_GBPS, 4)},
+                "fwd_ms_per_shot": round(fwd_ms / K, 2), "bwd_ms_per_shot": round(bwd_ms / K, 2),
+            }
+            if not args.no_cpu_baseline and world == 1:
+                out["cpu_baseline"] = cpu_baseline(args.nz, args.nx)
+            print(json.dumps(out))
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+        if world > 1:
+            td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+"""Host-side logic and the C-ABI surface (CPU only; no compute kernels are launched)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import problems as P
+from conftest import ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from sepfwi import _native
+    L = _native.lib()
+    hdr = open(os.path.join(ROOT, "include", "sepfwi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sepfwi_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sepfwi_version() >= 100
+    assert isinstance(L.sepfwi_last_error(), bytes)
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback(tmp_path):
+    """On a box without a HIP device the operator must raise (never compute on the CPU)."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from sepfwi import fwi_ops
+    from sepfwi._native import SepFwiError
+    pb = P.make_problem(str(tmp_path), nSteps=20)
+    lam, mu, den = pb["lame_init"]
+    with pytest.raises(SepFwiError) as e:
+        fwi_ops.obscalc(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    assert e.value.code == -4   # SEPFWI_EHIP
+
+
+def test_cpml_profiles_equal_oracle(oracle):
+    from sepfwi import _native
+    L = _native.lib()
+    for (n, npml, dh, f0, dt) in [(96, 10, 10.0, 25.0, 1e-3), (1064, 32, 10.0, 10.0, 1e-3), (265, 32, 20.0, 10.0, 2e-3), (70, 32, 5.0, 40.0, 2.5e-4)]:
+        arrs = [np.zeros(n, np.float32) for _ in range(6)]
+        _native.check(L.sepfwi_cpml_profiles(*[a.ctypes.data for a in arrs], n, npml, dh, f0, dt))
+        ref = oracle.cpml_init(n, npml, dh, f0, dt)
+        for k, a in zip(("K", "a", "b", "K_half", "a_half", "b_half"), arrs):
+            assert np.array_equal(a, ref[k]), (n, k)
+        # structure the kernels rely on: a == 0 outside the strips, K == 1 there, b == 1 there
+        inner = slice(npml + 1, n - npml - 1)
+        assert np.all(arrs[1][inner] == 0) and np.all(arrs[4][inner] == 0)
+        assert np.all(arrs[0][inner] == 1) and np.all(arrs[2][inner] == 1)
+
+
+def test_stf_taper_equals_oracle(oracle):
+    from sepfwi import _native
+    L = _native.lib()
+    rng = np.random.default_rng(0)
+    for nt, dt in [(1501, 2e-3), (4000, 1e-3), (300, 1e-3), (37, 4e-3)]:
+        s = rng.standard_normal(nt).astype(np.float32)
+        t = s.copy()
+        _native.check(L.sepfwi_stf_taper(t.ctypes.data, nt, dt, 0.001))
+        assert np.array_equal(t, oracle.window_stf(s, dt))
+        assert t[0] == 0.0
+
+
+def test_shot_split_equals_torch_linspace_truncation():
+    from sepfwi import _native
+    from sepfwi.ops import split_shots
+    L = _native.lib()
+    for g in list(range(1, 70)) + [128, 255, 256, 1000]:
+        for n in range(1, min(g, 16) + 1):
+            st = np.zeros(n + 1, np.int32)
+            _native.check(L.sepfwi_shot_split(g, n, st.ctypes.data))
+            assert st.tolist() == split_shots(g, n), (g, n)
+            assert st[0] == 0 and st[-1] == g and np.all(np.diff(st) >= 0)
+    st = np.zeros(4, np.int32)
+    assert L.sepfwi_shot_split(2, 3, st.ctypes.data) == -1     # ngpu > nshots (Torch_Fwi.cpp:49-52)
+    with pytest.raises(RuntimeError):
+        split_shots(2, 3)
+
+
+def test_json_errors_are_reported_not_fatal(tmp_path):
+    from sepfwi import _native
+    L = _native.lib()
+    z = np.zeros(4, np.float32)
+    ids = np.zeros(1, np.int32)
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"nz": 10, "nx": ')
+    rc = L.sepfwi_cufd(None, None, None, None, None, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 2, 0, 1,
+                       ids.ctypes.data, str(bad).encode())
+    assert rc == -5 and b"JSON" in L.sepfwi_last_error()
+    rc = L.sepfwi_cufd(None, None, None, None, None, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 2, 0, 1,
+                       ids.ctypes.data, str(tmp_path / "nope.json").encode())
+    assert rc == -2
+    rc = L.sepfwi_cufd(None, None, None, None, None, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 7, 0, 1,
+                       ids.ctypes.data, str(bad).encode())
+    assert rc == -1 and b"calc_id" in L.sepfwi_last_error()
+
+
+def test_para_and_survey_writers_schema(tmp_path):
+    pb = P.make_problem(str(tmp_path), nSteps=20, nshots=3)
+    para = json.loads(open(pb["para_fname"]).readline())
+    assert set(para) == {"nz", "nx", "dz", "dx", "nSteps", "dt", "f0", "nPoints_pml", "nPad", "survey_fname", "data_dir_name"}
+    assert isinstance(para["dt"], float)                         # Parameter.cpp:88 asserts IsDouble()
+    sv = json.loads(open(pb["survey_fname"]).readline())
+    assert sv["nShots"] == 3 and set(sv["shot0"]) == {"z_src", "x_src", "nrec", "z_rec", "x_rec"}
+    assert (pb["nz_pad"]) % 32 == 0
+
+
+def test_source_and_padding_helpers():
+    from sepfwi import utils as ft
+    s = ft.sourceGene(10.0, 1501, 0.002)
+    it = int(round(1.2 / 10.0 / 0.002))
+    assert s.dtype == np.float64 and abs(s[it] - 1e7) < 1e-3 and np.argmax(s) == it
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    p = ft.padding_numpy_array(a, 2, 3)
+    assert p.shape == (3 + 4 + 3, 4 + 4)
+    assert np.all(p[:2, 2:-2] == a[0]) and np.all(p[-5:, 2:-2] == a[-1]) and np.all(p[:, :2] == p[:, 2:3]) and np.all(p[:, -2:] == p[:, -3:-2])
+    t = torch.tensor(a)
+    tp, _, _ = ft.padding(t, t, t, 3, 4, 3, 4, 2, 3)
+    assert np.array_equal(tp.numpy(), p)
+    assert ft.nPad_for(101, 32) == 27 and ft.nPad_for(64, 32) == 32
+
+
+class _FakeOps:
+    """records the operator inputs; returns analytic 'gradients'"""
+    def __init__(self):
+        self.calls = []
+
+    def backward(self, Lambda, Mu, Den, Stf, ngpu, Shot_ids, para_fname):
+        self.calls.append((Lambda.detach().clone(), Mu.detach().clone(), Den.detach().clone(), ngpu, Shot_ids, para_fname))
+        return [torch.tensor([3.5]), torch.full_like(Lambda, 2.0), torch.full_like(Mu, -1.0), torch.full_like(Den, 0.5), torch.zeros_like(Stf)]
+
+
+def test_fwifunction_contract_and_module_chain_rule(monkeypatch, tmp_path):
+    import sepfwi.ops as ops
+    from sepfwi import modules as M
+    fake = _FakeOps()
+    monkeypatch.setattr(ops, "fwi_ops", fake)
+    pb = P.make_problem(str(tmp_path), nz=12, nx=14, nPml=4, nSteps=10, nshots=1, nPad=3)
+    vp = torch.tensor(pb["init"]["vp"], requires_grad=True)
+    vs = torch.tensor(pb["init"]["vs"], requires_grad=True)
+    rho = torch.tensor(pb["init"]["rho"], requires_grad=True)
+    mask = torch.zeros(pb["nz_pad"], pb["nx_pad"]); mask[4:16, 4:18] = 1.0
+    fwi = M.FWI(vp, vs, rho, pb["Stf"], pb["opt"], Mask=mask)
+    assert [n for n, _ in fwi.named_parameters()] == ["Vp", "Vs", "Den"]
+    assert set(dict(fwi.named_buffers())) == {"Vp_ref", "Vs_ref", "Den_ref"}
+    loss = fwi(pb["Shot_ids"], ngpu=1)
+    assert float(loss) == 3.5
+    (10.0 * loss).backward()      # grad_misfit is ignored by the reference's Function (FWI_ops.py:54-63)
+    lam, mu, den, ngpu, ids, pf = fake.calls[0]
+    assert lam.shape == (pb["nz_pad"], pb["nx_pad"]) and pf == pb["para_fname"] and ngpu == 1
+    assert torch.allclose(mu[4:16, 4:18], torch.tensor(pb["init"]["vs"]) ** 2 * torch.tensor(pb["init"]["rho"]) / 1e6)
+    # chain rule with gL=2, gM=-1, gD=0.5 on the unmasked physical cells
+    vp0, vs0, r0 = [torch.tensor(pb["init"][k]) for k in ("vp", "vs", "rho")]
+    assert torch.allclose(fwi.Vp.grad, 2.0 * 2 * vp0 * r0 / 1e6, rtol=1e-5)
+    assert torch.allclose(fwi.Vs.grad, (2.0 * (-4 * vs0) + (-1.0) * 2 * vs0) * r0 / 1e6, rtol=1e-5)
+    assert torch.allclose(fwi.Den.grad, 2.0 * (vp0 ** 2 - 2 * vs0 ** 2) / 1e6 - 1.0 * vs0 ** 2 / 1e6 + 0.5, rtol=1e-5)
+
+
+def test_obj_wrapper_roundtrip(monkeypatch, tmp_path):
+    import sepfwi.ops as ops
+    from sepfwi import modules as M
+    from sepfwi.obj_wrapper import PyTorchObjective
+    monkeypatch.setattr(ops, "fwi_ops", _FakeOps())
+    pb = P.make_problem(str(tmp_path), nz=12, nx=14, nPml=4, nSteps=10, nshots=1, nPad=3)
+    T = lambda k: torch.tensor(pb["init"][k], requires_grad=True)
+    fwi = M.FWI(T("vp"), T("vs"), T("rho"), pb["Stf"], pb["opt"])
+    obj = PyTorchObjective(fwi, lambda: fwi(pb["Shot_ids"], ngpu=1))
+    assert obj.x0.dtype == np.float64 and obj.x0.size == 3 * 12 * 14 and obj.bounds is None
+    jac = obj.jac
+    assert obj.fun(obj.x0) == 3.5
+    g = jac(obj.x0)
+    assert g.dtype == np.float64 and g.shape == obj.x0.shape and np.all(np.isfinite(g))
