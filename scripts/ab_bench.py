@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""A/B timing of kernel options in ONE process on one GPU (interleaved rounds, cdna guide rule 24).
+usage: python scripts/ab_bench.py --nsteps 400 --rounds 3 "bz=4,xcd_remap=0" "bz=4,xcd_remap=1" ...
+Prints per-variant forward / backward microseconds per time step (HIP events on the session stream)."""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sep-2023_amd")]
+import numpy as np
+import torch
+
+import bench
+from sepfwi import _native, fwi_ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+")
+    ap.add_argument("--nsteps", type=int, default=400)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--nz", type=int, default=1000)
+    ap.add_argument("--nx", type=int, default=2000)
+    a = ap.parse_args()
+    L = _native.lib()
+    dev = torch.device("cuda", 0)
+    work = tempfile.mkdtemp(prefix="sepfwi_ab_")
+    try:
+        pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, 1)
+        lt, mt, dt_ = [t.to(dev) for t in pb["lame_true"]]
+        lam, mu, den = [t.to(dev) for t in pb["lame_init"]]
+        ids = torch.tensor([0], dtype=torch.int32)
+        fwi_ops._cufd(2, 0, lt, mt, dt_, pb["Stf"], ids, pb["para_fname"])
+        res = {v: [] for v in a.variants}
+        ref = None
+        for r in range(a.rounds + 1):
+            for v in a.variants:
+                for kv in v.split(","):
+                    if not kv:
+                        continue
+                    k, val = kv.split("=")
+                    _native.check(L.sepfwi_set_option(k.encode(), int(val)))
+                out = fwi_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+                st = fwi_ops.stats(pb["para_fname"], 0)
+                if r > 0:
+                    res[v].append((st["fwd_ms"] * 1e3 / st["fwd_steps"], st["bwd_ms"] * 1e3 / st["bwd_steps"]))
+                sig = (float(out[0]), float(out[1].abs().sum()), float(out[3].abs().sum()))
+                if ref is None:
+                    ref = sig
+                dev_ = max(abs(x - y) / max(abs(y), 1e-30) for x, y in zip(sig, ref))
+                if dev_ > 1e-5:
+                    print("WARNING variant %s result deviates from first variant by %.2e" % (v, dev_))
+        nc = pb["n_c"]
+        for v in a.variants:
+            f = np.array([x[0] for x in res[v]]); b = np.array([x[1] for x in res[v]])
+            tot = np.median(f) + np.median(b)
+            print("%-40s fwd %7.2f us (min %7.2f)  bwd %7.2f us (min %7.2f)  -> %6.2f Gcell-updates/s" %
+                  (v, np.median(f), f.min(), np.median(b), b.min(), 3 * nc / tot / 1e3))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

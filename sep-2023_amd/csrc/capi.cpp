@@ -4,6 +4,7 @@
 #include <cstring>
 #include <string>
 
+#include "kernels.hpp"
 #include "session.hpp"
 
 using namespace sepfwi;
@@ -117,8 +118,8 @@ int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out) {
 }
 
 int sepfwi_set_option(const char *name, int value) {
-    (void)value;
-    return fail(SEPFWI_EINVAL, std::string("unknown option '") + (name ? name : "") + "'");
+    if (set_kernel_option(name, value) == 0) return SEPFWI_OK;
+    return fail(SEPFWI_EINVAL, std::string("unknown option or bad value: '") + (name ? name : "") + "'");
 }
 
 }  // extern "C"

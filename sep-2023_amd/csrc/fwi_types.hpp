@@ -27,6 +27,9 @@ struct Grid {
     // boundary frame geometry (Boundary.cu:17-27): rows/cols [nPml-2, nPml-2+n?Bnd)
     int nzBnd, nxBnd;  // nzc - 2 nPml + 4, nx - 2 nPml + 4
     int frame_len;     // floats per field per time step in OUR packing (no duplicated corners)
+    // launch tiling of the field kernels (filled by the launchers): gx x gy tiles of 64 columns x bz rows,
+    // optionally renumbered so that each XCD (blockIdx % 8) owns a contiguous band of tiles
+    int gx, gy, bz, xcd_remap;
 };
 
 // Five wavefields (or their adjoint twins), each nzc*pitch floats.

@@ -22,6 +22,8 @@
 // shifted re-reads that hit the same lines in the vector L1).
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "kernels.hpp"
 
 namespace sepfwi {
@@ -31,7 +33,11 @@ namespace {
 constexpr float C1 = 9.0f / 8.0f;   // el_stress.cu:42
 constexpr float C2 = 1.0f / 24.0f;  // el_stress.cu:43
 constexpr int BX = 64;              // threads along x  (one wave)
-constexpr int BZ = 4;               // waves per block, one row each
+constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
+
+int g_opt_bz = 2;                   // waves (rows) per block
+int g_opt_xcd_remap = 1;            // 1: each XCD gets a contiguous band of tiles
+int g_opt_bwd_fuse = 1;             // 1: two fused kernels per backward step instead of four
 
 // backward-staggered first derivative D-:  (c1 (f0 - fm1) - c2 (fp1 - fm2)) / h
 __device__ __forceinline__ float dminus(float fm2, float fm1, float f0, float fp1, float rh) {
@@ -65,9 +71,19 @@ struct Cell {
 
 __device__ __forceinline__ Cell my_cell(const Grid &g) {
     Cell c;
-    c.x = blockIdx.x * BX + (threadIdx.x & (BX - 1));
+    // tile id: blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an L2); with xcd_remap the
+    // logical tile order gives each XCD a contiguous band of rows so that z-halo rows are re-read from
+    // the SAME L2 instead of being fetched once per XCD.
+    int t = blockIdx.x;
+    if (g.xcd_remap) {
+        const int per = (g.gx * g.gy + 7) >> 3;
+        t = (t & 7) * per + (t >> 3);
+    }
+    const int ty = t / g.gx, tx = t - ty * g.gx;
+    c.x = tx * BX + (threadIdx.x & (BX - 1));
     // row is wave-uniform: keep it in an SGPR so the z-profile loads and PML tests are scalar
-    c.z = __builtin_amdgcn_readfirstlane(blockIdx.y * BZ + (threadIdx.x >> 6));
+    c.z = __builtin_amdgcn_readfirstlane(ty * g.bz + (int)(threadIdx.x >> 6));
+    if (ty >= g.gy) c.z = g.nz + 1;  // surplus block of the remapped numbering: out of range
     c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
     return c;
 }
@@ -78,11 +94,10 @@ __device__ __forceinline__ Cell my_cell(const Grid &g) {
 // stress update
 // ---------------------------------------------------------------------------------------------
 template <bool FWD, bool SAVE>
-__global__ __launch_bounds__(BX *BZ) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
-                                                   float *__restrict__ frame_t,  // this step's 5*frame_len block
-                                                   int z_src, int x_src, float src_amp,  // scale*stf[it]*dt
-                                                   Fields adj, ImgAcc acc) {
-    const Cell c = my_cell(g);
+__device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
+                                            const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
+                                            int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
+                                            const Fields &adj, const ImgAcc &acc) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -179,11 +194,10 @@ __global__ __launch_bounds__(BX *BZ) void k_stress(Grid g, Fields f, PmlMem m, M
 // velocity update
 // ---------------------------------------------------------------------------------------------
 template <bool FWD>
-__global__ __launch_bounds__(BX *BZ) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
-                                                     const float *__restrict__ frame_t, int z_src, int x_src,
-                                                     float src_rxz, float *__restrict__ stf_grad_it,
-                                                     Fields adj, ImgAcc acc) {
-    const Cell c = my_cell(g);
+__device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
+                                              const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
+                                              float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
+                                              const ImgAcc &acc) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -245,8 +259,8 @@ __global__ __launch_bounds__(BX *BZ) void k_velocity(Grid g, Fields f, PmlMem m,
 // The a*dpsi terms are evaluated only where a != 0 (inside the PML strips; a is exactly 0 elsewhere,
 // utilities.cu:272-275,347-353), which lets k_stress_adj keep psi only near the strips.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BX *BZ) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
-    const Cell c = my_cell(g);
+__device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
+                                                  const Media &md, const PmlCoef &pc) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
     const size_t i = c.i;
@@ -289,8 +303,8 @@ __global__ __launch_bounds__(BX *BZ) void k_velocity_adj(Grid g, Fields f, PmlMe
 // stencils multiplied by a (zero outside the strips), so updating them on the strips widened by
 // the stencil radius (2) gives identical results.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BX *BZ) void k_stress_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
-    const Cell c = my_cell(g);
+__device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
+                                                const Media &md, const PmlCoef &pc) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
     const size_t i = c.i;
@@ -326,6 +340,52 @@ __global__ __launch_bounds__(BX *BZ) void k_stress_adj(Grid g, Fields f, PmlMem 
     f.szz[i] = szz;
     if (wx) m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
     if (wz) m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: one body each (the reference's launch structure) ...
+// ---------------------------------------------------------------------------------------------
+template <bool FWD, bool SAVE>
+__global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
+                                                 int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
+    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
+}
+template <bool FWD>
+__global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
+                                                   const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
+                                                   float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
+    velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
+}
+__global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    velocity_adj_body(g, my_cell(g), f, m, md, pc);
+}
+__global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    stress_adj_body(g, my_cell(g), f, m, md, pc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ... and the backward step fused ACROSS its two independent chains (option "bwd_fuse" = 1):
+//   k_bwd_velocity = reverse-time velocity (+ source_grad, rho imaging, frame restore) and adjoint velocity
+//   k_bwd_stress   = reverse-time stress (+ source removal, lambda/mu imaging, frame restore) and adjoint stress
+// Both halves of a kernel only READ the stress-type (resp. velocity-type) arrays through their stencils and
+// read-modify-write their own cell of the velocity-type (resp. stress-type) arrays, so there is no
+// inter-thread hazard and no halo recomputation.  Order inside a thread keeps the reference semantics:
+// the imaging condition sees the adjoint field of the START of the step (libCUFD.cu:553-631: imaging
+// kernels run before the adjoint kernels), and the residual injection still happens between the two
+// kernels (k_inject).  4 field launches -> 2; 240 -> 200 algorithmic bytes per cell.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MAXT) void k_bwd_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
+                                                       const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
+                                                       float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
+    const Cell c = my_cell(g);
+    velocity_body<false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
+    velocity_adj_body(g, c, adj, m, md, pc);
+}
+__global__ __launch_bounds__(MAXT) void k_bwd_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
+                                                     int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
+    const Cell c = my_cell(g);
+    stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
+    stress_adj_body(g, c, adj, m, md, pc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -503,47 +563,88 @@ __global__ void k_finalize_gradients(Grid g, Media md, ImgAcc acc, float *__rest
 // =============================================================================================
 // launchers
 // =============================================================================================
-static inline dim3 field_grid(const Grid &g) { return dim3((g.nx + BX - 1) / BX, (g.nzc + BZ - 1) / BZ); }
+static inline Grid tiled(const Grid &g0) {
+    Grid g = g0;
+    g.bz = g_opt_bz;
+    g.gx = (g.nx + BX - 1) / BX;
+    g.gy = (g.nzc + g.bz - 1) / g.bz;
+    g.xcd_remap = g_opt_xcd_remap;
+    return g;
+}
+static inline dim3 field_grid(const Grid &g) {
+    const int nb = g.gx * g.gy;
+    return dim3(g.xcd_remap ? ((nb + 7) / 8) * 8 : nb);
+}
+#define BLOCK dim3(BX *g.bz)
 
-void launch_stress_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
+int get_kernel_option_bwd_fuse() { return g_opt_bwd_fuse; }
+
+int set_kernel_option(const char *name, int value) {
+    const std::string n(name ? name : "");
+    if (n == "bz" && value >= 1 && value <= 16) { g_opt_bz = value; return 0; }
+    if (n == "xcd_remap") { g_opt_xcd_remap = value ? 1 : 0; return 0; }
+    if (n == "bwd_fuse") { g_opt_bwd_fuse = value ? 1 : 0; return 0; }
+    return -1;
+}
+
+void launch_stress_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
                        int z_src, int x_src, float src_amp) {
+    const Grid g = tiled(g0);
     Fields none{};
     ImgAcc na{};
     if (frame_t)
-        hipLaunchKernelGGL((k_stress<true, true>), field_grid(g), dim3(BX * BZ), 0, st, g, f, m, md, pc, frame_t, z_src,
+        hipLaunchKernelGGL((k_stress<true, true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
                            x_src, src_amp, none, na);
     else
-        hipLaunchKernelGGL((k_stress<true, false>), field_grid(g), dim3(BX * BZ), 0, st, g, f, m, md, pc, frame_t, z_src,
+        hipLaunchKernelGGL((k_stress<true, false>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
                            x_src, src_amp, none, na);
 }
 
-void launch_velocity_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc) {
+void launch_velocity_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    const Grid g = tiled(g0);
     Fields none{};
     ImgAcc na{};
-    hipLaunchKernelGGL((k_velocity<true>), field_grid(g), dim3(BX * BZ), 0, st, g, f, m, md, pc, (const float *)nullptr,
+    hipLaunchKernelGGL((k_velocity<true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, (const float *)nullptr,
                        -1, -1, 0.0f, (float *)nullptr, none, na);
 }
 
-void launch_velocity_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
+void launch_velocity_rev(hipStream_t st, const Grid &g0, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
                          int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0);
     PmlMem nm{};
-    hipLaunchKernelGGL((k_velocity<false>), field_grid(g), dim3(BX * BZ), 0, st, g, f, nm, md, pc, frame_t, z_src, x_src,
+    hipLaunchKernelGGL((k_velocity<false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src, x_src,
                        src_rxz, stf_grad_it, adj, acc);
 }
 
-void launch_stress_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, float *frame_t, int z_src,
+void launch_stress_rev(hipStream_t st, const Grid &g0, Fields f, Media md, PmlCoef pc, float *frame_t, int z_src,
                        int x_src, float src_amp, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0);
     PmlMem nm{};
-    hipLaunchKernelGGL((k_stress<false, false>), field_grid(g), dim3(BX * BZ), 0, st, g, f, nm, md, pc, frame_t, z_src,
+    hipLaunchKernelGGL((k_stress<false, false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src,
                        x_src, src_amp, adj, acc);
 }
 
-void launch_velocity_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc) {
-    hipLaunchKernelGGL(k_velocity_adj, field_grid(g), dim3(BX * BZ), 0, st, g, adj, m, md, pc);
+void launch_velocity_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Media md, PmlCoef pc) {
+    const Grid g = tiled(g0);
+    hipLaunchKernelGGL(k_velocity_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
-void launch_stress_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc) {
-    hipLaunchKernelGGL(k_stress_adj, field_grid(g), dim3(BX * BZ), 0, st, g, adj, m, md, pc);
+void launch_stress_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Media md, PmlCoef pc) {
+    const Grid g = tiled(g0);
+    hipLaunchKernelGGL(k_stress_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
+}
+
+void launch_bwd_velocity(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
+                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0);
+    hipLaunchKernelGGL(k_bwd_velocity, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it,
+                       adj, acc);
+}
+
+void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
+                       int x_src, float src_amp, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0);
+    hipLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

@@ -15,6 +15,11 @@ void launch_stress_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoe
                        int x_src, float src_amp, Fields adj, ImgAcc acc);
 void launch_velocity_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
 void launch_stress_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
+void launch_bwd_velocity(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
+                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc);
+void launch_bwd_stress(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
+                       int x_src, float src_amp, Fields adj, ImgAcc acc);
+int get_kernel_option_bwd_fuse();
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps);
 void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t);
@@ -25,5 +30,8 @@ void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const
                        float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, unsigned int *cp2_max_bits);
 void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
                                float *gDen);
+
+// run-time kernel options ("bz": rows per block 1..16, "xcd_remap": 0/1); returns 0 or -1
+int set_kernel_option(const char *name, int value);
 
 }  // namespace sepfwi

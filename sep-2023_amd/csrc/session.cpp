@@ -346,15 +346,23 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             HIP_OK(hipMemsetAsync(state_ + 5 * n, 0, 13 * n * sizeof(float), st));
             HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
             HIP_OK(hipEventRecord(ev_[2], st));
+            const bool fuse = get_kernel_option_bwd_fuse() != 0;
             for (int it = nSteps - 2; it >= 0; it--) {
                 float *frame_t = frame_ + (size_t)it * 5 * (size_t)g.frame_len;
                 const float amp = src_scale * stf_s[it] * par_.dt;
-                launch_velocity_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
-                launch_stress_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
-                launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
-                launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
-                launch_stress_adj(st, g, adj_, mem_, md_, pc_);
-                launches_ += 5;
+                if (fuse) {
+                    launch_bwd_velocity(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
+                    launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
+                    launch_bwd_stress(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                    launches_ += 3;
+                } else {
+                    launch_velocity_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
+                    launch_stress_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                    launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
+                    launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
+                    launch_stress_adj(st, g, adj_, mem_, md_, pc_);
+                    launches_ += 5;
+                }
             }
             HIP_OK(hipEventRecord(ev_[3], st));
             bwd_steps_ += nSteps - 1;
