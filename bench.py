@@ -32,6 +32,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_UPDATE_FWDADJ = 184.0 / 3.0   # 60 B fwd + 124 B bwd per cell per step = 61.33 B / cell-update
 BYTES_FWD = 60.0
+# Dominant kernel of the sweep: k_bwd_stress (reverse-time stress + lambda/mu imaging + adjoint stress).  Of the
+# 124 algorithmic bytes per cell of a backward step it owns the arrays it read-modify-writes and the
+# coefficients only it needs: szz,sxx,sxz r/w 24 + adjoint szz,sxx,sxz r/w 24 + lambda,mu,ave_mu 12 + grad lambda,mu
+# r/w 16 = 76 B per cell per launch (k_bwd_velocity owns the other 48 B); DESIGN.md "Kernels and rooflines".
+BYTES_K_BWD_STRESS = 76.0
 
 
 def marmousi_style(nz, nx, seed=2023):
@@ -154,6 +159,8 @@ def main():
                 return fwi_ops.forward(lam, mu, den, Stf, local, ids[rank:rank + 1], pb["para_fname"])
             return fwi_ops.backward(lam, mu, den, Stf, world, ids, pb["para_fname"])
 
+        from sepfwi import _native
+        _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_stress launch
         for w in range(W):
             step(w % per_rank_shots)
         torch.cuda.synchronize()
@@ -162,11 +169,14 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fwd_ms = bwd_ms = 0.0
+        probe_us, probe_n = 0.0, 0
         for s in range(K):
             step(s)
             st = fwi_ops.stats(pb["para_fname"], local)
             fwd_ms += st["fwd_ms"]
             bwd_ms += st["bwd_ms"]
+            probe_us += st["probe_kernel_us"] * st["probe_calls"]
+            probe_n += st["probe_calls"]
         torch.cuda.synchronize()
         if world > 1:
             td.barrier()
@@ -184,14 +194,23 @@ def main():
             # roofline of the dominant kernel group, measured live with HIP events on the session stream
             # (sepfwi_stats.fwd_ms / bwd_ms): algorithmic bytes per time step / measured time per time step.
             nst = K * (args.nsteps - 1)
-            if args.mode == "fwdadj":
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
+            if os.path.exists(tf) and args.nz == 1000 and args.nx == 2000:
+                traffic = json.load(open(tf)).get("k_bwd_stress_bytes_per_launch")
+            if args.mode == "fwdadj" and probe_n > 0:
+                per_step_us = probe_us / probe_n
+                ach = pb["n_c"] * BYTES_K_BWD_STRESS / (per_step_us * 1e-6) / 1e9
+                kern = "k_bwd_stress (%d launches sampled with HIP events in the timed region)" % probe_n
+            elif args.mode == "fwdadj":
                 per_step_us = bwd_ms * 1e3 / nst
                 ach = pb["n_c"] * 124.0 / (per_step_us * 1e-6) / 1e9
-                kern = "backward time step (k_velocity<REV>+k_stress<REV>+k_velocity_adj+k_inject+k_stress_adj)"
+                kern = "whole backward time step"
             else:
                 per_step_us = fwd_ms * 1e3 / nst
                 ach = pb["n_c"] * BYTES_FWD / (per_step_us * 1e-6) / 1e9
-                kern = "forward time step (k_stress<FWD>+k_velocity<FWD>+k_record)"
+                kern = "whole forward time step (k_stress<FWD> + k_velocity<FWD>)"
+                traffic = None
             out = {
                 "metric": "Gcell-updates/s (fwd+adj), 2000x1000 grid x 4000 steps" if args.mode == "fwdadj" else "Gcell-updates/s (fwd)",
                 "value": round(value, 4), "unit": "Gcell-updates/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -202,10 +221,11 @@ def main():
                                                                         pb["nrec"], "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
                            "cell_updates_per_shot": updates_per_shot, "parallelism": "shots x%d" % world},
                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kern,
+                             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": kern,
                              "avg_us": round(per_step_us, 2),
                              "whole_job_frac": round(value * (BYTES_PER_UPDATE_FWDADJ if args.mode == "fwdadj" else BYTES_FWD) / world / HBM_PEAK_GBPS, 4)},
                 "fwd_ms_per_shot": round(fwd_ms / K, 2), "bwd_ms_per_shot": round(bwd_ms / K, 2),
+                "fwd_us_per_time_step": round(fwd_ms * 1e3 / nst, 2), "bwd_us_per_time_step": round(bwd_ms * 1e3 / nst, 2),
             }
             if not args.no_cpu_baseline and world == 1:
                 out["cpu_baseline"] = cpu_baseline(args.nz, args.nx)

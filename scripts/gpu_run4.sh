@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+( timeout 900 python -m pytest tests -m gpu -x -q ) > gpurun_out/pytest_gpu.log 2>&1
+tail -5 gpurun_out/pytest_gpu.log
+timeout 900 python scripts/ab_bench.py --nsteps 300 --rounds 3 "fwd_fuse=0" "fwd_fuse=1" > gpurun_out/ab4.log 2>&1
+cat gpurun_out/ab4.log
+./scripts/probes/bw_probe 2>&1 | grep -E "ping-pong|MB set" 

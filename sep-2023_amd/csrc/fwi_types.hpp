@@ -67,6 +67,42 @@ struct ImgAcc {
     float *lam, *mu, *xz, *a, *b;
 };
 
+// Receivers that form a horizontal line (the usual horizontal DAS fibre): channel r sits at (z, x0 + r).
+// Lets the field kernels sample / inject at their own cells with no extra launch and no lookup.
+struct LineRec {
+    int z, x0, n;                // n == 0: survey is not a line (separate k_record / k_inject launches)
+    float *d_vx, *d_vz, *d_ett;  // forward: this step's seismogram columns (each may be null)
+    const float *res;            // backward: this step's residual column
+};
+
+// Receivers grouped by the tile (of the fused forward kernel) that owns their cell: CSR over tiles.
+struct RecTiles {
+    const int *off;   // [ntiles+1]
+    const int *cell;  // z*pitch + x
+    const int *rec;   // receiver index (column of the seismogram)
+};
+
+// Arguments of the fused forward step (fwd_fused.hip).  Arrays come as bundles "base + k*n":
+//   fo/fn : vz, vx, szz, sxx, sxz             (old / new wavefield)
+//   mo/mn : psi(dvz_dz), psi(dvz_dx), psi(dvx_dz), psi(dvx_dx)   (old / new stress-side C-PML memory)
+//   mv    : psi(dszz_dz), psi(dsxz_dx), psi(dsxz_dz), psi(dsxx_dx)   (velocity-side, in place)
+//   media : lam, mu, ave_mu, byc_a, byc_b ;   cz/cx: a, b, 1/K, a_half, b_half, 1/K_half  (6 x nzc / 6 x nx)
+struct FwdFusedArgs {
+    const float *fo;
+    float *fn;
+    const float *mo;
+    float *mn;
+    float *mv;
+    const float *media, *cz, *cx;
+    float *frame_t;
+    const int *rt_off, *rt_cell, *rt_rec;
+    float *d_pr, *d_vx, *d_vz, *d_ett;
+    unsigned n;
+    int z_src, x_src;
+    float src_amp;
+    int comps;
+};
+
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step
     float *buf;  // [nSteps][5][frame_len]  order: szz, sxz, sxx, vz, vx (Boundary.cu:57-80)
 };

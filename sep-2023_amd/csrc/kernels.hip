@@ -21,48 +21,28 @@
 // x of one row, so every global access of a wave is one 256-B line-aligned segment (plus the +-1/+-2
 // shifted re-reads that hit the same lines in the vector L1).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <string>
 
+#include "device_common.hpp"
 #include "kernels.hpp"
 
 namespace sepfwi {
 
+using namespace dev;
+
 namespace {
 
-constexpr float C1 = 9.0f / 8.0f;   // el_stress.cu:42
-constexpr float C2 = 1.0f / 24.0f;  // el_stress.cu:43
 constexpr int BX = 64;              // threads along x  (one wave)
 constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
 
 int g_opt_bz = 2;                   // waves (rows) per block
 int g_opt_xcd_remap = 1;            // 1: each XCD gets a contiguous band of tiles
 int g_opt_bwd_fuse = 1;             // 1: two fused kernels per backward step instead of four
-
-// backward-staggered first derivative D-:  (c1 (f0 - fm1) - c2 (fp1 - fm2)) / h
-__device__ __forceinline__ float dminus(float fm2, float fm1, float f0, float fp1, float rh) {
-    return (C1 * (f0 - fm1) - C2 * (fp1 - fm2)) * rh;
-}
-// forward-staggered first derivative D+:   (c1 (fp1 - f0) - c2 (fp2 - fm1)) / h
-__device__ __forceinline__ float dplus(float fm1, float f0, float fp1, float fp2, float rh) {
-    return (C1 * (fp1 - f0) - C2 * (fp2 - fm1)) * rh;
-}
-
-// Slot of cell (z,x) in the packed boundary frame, or -1.  The frame is the 5-cell-thick ring
-// rows/cols [nPml-2, nPml+2] U [n-nPml-3, n-nPml+1] of the reference (utilities.cu:362-392) without
-// its duplicated corners:  [top 5 rows][bottom 5 rows][middle rows: 5 left + 5 right cells].
-__device__ __forceinline__ int frame_slot(const Grid &g, int z, int x) {
-    const int zf = z - (g.nPml - 2), xf = x - (g.nPml - 2);
-    if (zf < 0 || zf >= g.nzBnd || xf < 0 || xf >= g.nxBnd) return -1;
-    if (zf < 5) return zf * g.nxBnd + xf;
-    if (zf >= g.nzBnd - 5) return (5 + zf - (g.nzBnd - 5)) * g.nxBnd + xf;
-    const int base = 10 * g.nxBnd + (zf - 5) * 10;
-    if (xf < 5) return base + xf;
-    if (xf >= g.nxBnd - 5) return base + 5 + (xf - (g.nxBnd - 5));
-    return -1;
-}
-
-__device__ __forceinline__ bool in_pml_z(const Grid &g, int z) { return z < g.nPml || z > g.nzc - g.nPml - 1; }
+int g_opt_fwd_fuse = 0;             // 1: one fused kernel per forward step (fwd_fused.hip)
+int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
+int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
 struct Cell {
     int z, x;
@@ -97,7 +77,7 @@ template <bool FWD, bool SAVE>
 __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
-                                            const Fields &adj, const ImgAcc &acc) {
+                                            const Fields &adj, const ImgAcc &acc, const LineRec &lr) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -117,8 +97,19 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
         }
         if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_stress.cu:52
 
-        float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
-        float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
+        const float vz0 = f.vz[i], vx0 = f.vx[i], vxm1 = f.vx[i - 1];
+        if (lr.n && z == lr.z) {
+            // line receivers: seismogram column `it` = velocities at the START of step `it`, which this kernel
+            // only reads (recording_vx / _vz / _exx, utilities.cu:593-602,645-677)
+            const int r = x - lr.x0;
+            if (r >= 0 && r < lr.n) {
+                if (lr.d_vx) lr.d_vx[r] = vx0;
+                if (lr.d_vz) lr.d_vz[r] = vz0;
+                if (lr.d_ett) lr.d_ett[r] = vx0 - vxm1;
+            }
+        }
+        float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], vz0, f.vz[i + P], g.rdz);
+        float dvx_dx = dminus(f.vx[i - 2], vxm1, vx0, f.vx[i + 1], g.rdx);
         float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
         float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
 
@@ -260,7 +251,7 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
 // utilities.cu:272-275,347-353), which lets k_stress_adj keep psi only near the strips.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
-                                                  const Media &md, const PmlCoef &pc) {
+                                                  const Media &md, const PmlCoef &pc, const LineRec &lr) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
     const size_t i = c.i;
@@ -278,7 +269,17 @@ __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, 
     if (px) upd += pc.a_x[x] * -dplus(m.dvx_dx[i - 1], m.dvx_dx[i], m.dvx_dx[i + 1], m.dvx_dx[i + 2], g.rdx);
     if (pz) upd += pc.a_zh[z] * -dminus(m.dvx_dz[i - 2 * P], m.dvx_dz[i - P], m.dvx_dz[i], m.dvx_dz[i + P], g.rdz);
     const float vx = f.vx[i] + upd;
-    f.vx[i] = vx;
+    {
+        // res_injection_exx (utilities.cu:605-615) for line receivers, applied by the thread that owns the cell:
+        // vx_adj(z,x) += r[x]; vx_adj(z,x) -= r[x+1]   (after this kernel's update, libCUFD.cu:585-610)
+        float vs = vx;
+        if (lr.n && z == lr.z) {
+            const int r = x - lr.x0;
+            if (r >= 0 && r < lr.n) vs += lr.res[r];
+            if (r + 1 >= 0 && r + 1 < lr.n) vs -= lr.res[r + 1];
+        }
+        f.vx[i] = vs;
+    }
     const float bb = md.byc_b[i];
     if (px) m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
     if (pz) m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
@@ -347,8 +348,8 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
 // ---------------------------------------------------------------------------------------------
 template <bool FWD, bool SAVE>
 __global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
-                                                 int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
-    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
+                                                 int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc, LineRec lr) {
+    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr);
 }
 template <bool FWD>
 __global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, M
     velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
-    velocity_adj_body(g, my_cell(g), f, m, md, pc);
+    velocity_adj_body(g, my_cell(g), f, m, md, pc, LineRec{});
 }
 __global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     stress_adj_body(g, my_cell(g), f, m, md, pc);
@@ -376,15 +377,15 @@ __global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, Fields f, PmlMem m,
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MAXT) void k_bwd_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
                                                        const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
-                                                       float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
+                                                       float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
     const Cell c = my_cell(g);
     velocity_body<false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
-    velocity_adj_body(g, c, adj, m, md, pc);
+    velocity_adj_body(g, c, adj, m, md, pc, lr);
 }
 __global__ __launch_bounds__(MAXT) void k_bwd_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
                                                      int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
     const Cell c = my_cell(g);
-    stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
+    stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
     stress_adj_body(g, c, adj, m, md, pc);
 }
 
@@ -579,25 +580,39 @@ static inline dim3 field_grid(const Grid &g) {
 
 int get_kernel_option_bwd_fuse() { return g_opt_bwd_fuse; }
 
+int get_kernel_option(const char *name) {
+    const std::string n(name ? name : "");
+    if (n == "bz") return g_opt_bz;
+    if (n == "xcd_remap") return g_opt_xcd_remap;
+    if (n == "bwd_fuse") return g_opt_bwd_fuse;
+    if (n == "fwd_fuse") return g_opt_fwd_fuse;
+    if (n == "line_fuse") return g_opt_line_fuse;
+    if (n == "probe") return g_opt_probe;
+    return -1;
+}
+
 int set_kernel_option(const char *name, int value) {
     const std::string n(name ? name : "");
     if (n == "bz" && value >= 1 && value <= 16) { g_opt_bz = value; return 0; }
     if (n == "xcd_remap") { g_opt_xcd_remap = value ? 1 : 0; return 0; }
     if (n == "bwd_fuse") { g_opt_bwd_fuse = value ? 1 : 0; return 0; }
+    if (n == "fwd_fuse") { g_opt_fwd_fuse = value ? 1 : 0; return 0; }
+    if (n == "line_fuse") { g_opt_line_fuse = value ? 1 : 0; return 0; }
+    if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
     return -1;
 }
 
 void launch_stress_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
-                       int z_src, int x_src, float src_amp) {
+                       int z_src, int x_src, float src_amp, LineRec lr) {
     const Grid g = tiled(g0);
     Fields none{};
     ImgAcc na{};
     if (frame_t)
         hipLaunchKernelGGL((k_stress<true, true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
-                           x_src, src_amp, none, na);
+                           x_src, src_amp, none, na, lr);
     else
         hipLaunchKernelGGL((k_stress<true, false>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
-                           x_src, src_amp, none, na);
+                           x_src, src_amp, none, na, lr);
 }
 
 void launch_velocity_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc) {
@@ -621,7 +636,7 @@ void launch_stress_rev(hipStream_t st, const Grid &g0, Fields f, Media md, PmlCo
     const Grid g = tiled(g0);
     PmlMem nm{};
     hipLaunchKernelGGL((k_stress<false, false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src,
-                       x_src, src_amp, adj, acc);
+                       x_src, src_amp, adj, acc, LineRec{});
 }
 
 void launch_velocity_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Media md, PmlCoef pc) {
@@ -635,16 +650,20 @@ void launch_stress_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Med
 }
 
 void launch_bwd_velocity(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
-                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
+                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
     const Grid g = tiled(g0);
     hipLaunchKernelGGL(k_bwd_velocity, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it,
-                       adj, acc);
+                       adj, acc, lr);
 }
 
 void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
-                       int x_src, float src_amp, Fields adj, ImgAcc acc) {
+                       int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0);
-    hipLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
+    if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
+        hipExtLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, f, m, md, pc, frame_t, z_src,
+                              x_src, src_amp, adj, acc);
+    else
+        hipLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

@@ -7,7 +7,7 @@
 namespace sepfwi {
 
 void launch_stress_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
-                       int z_src, int x_src, float src_amp);
+                       int z_src, int x_src, float src_amp, LineRec lr);
 void launch_velocity_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc);
 void launch_velocity_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
                          int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc);
@@ -16,10 +16,15 @@ void launch_stress_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoe
 void launch_velocity_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
 void launch_stress_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
 void launch_bwd_velocity(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
-                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc);
+                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr);
 void launch_bwd_stress(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
-                       int x_src, float src_amp, Fields adj, ImgAcc acc);
+                       int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr);
 int get_kernel_option_bwd_fuse();
+int get_kernel_option(const char *name);
+// fused forward step (fwd_fused.hip)
+void fwd_fused_tile_shape(int *rows, int *cols);
+void launch_fwd_fused(hipStream_t st, const Grid &g, const FwdFusedArgs &a, int xcd_remap);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps);
 void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t);

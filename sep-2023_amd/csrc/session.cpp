@@ -66,6 +66,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     HIP_OK(hipSetDevice(gpu_id_));
     HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     for (auto &e : ev_) HIP_OK(hipEventCreate(&e));
+    for (auto &e : probe_ev_) HIP_OK(hipEventCreate(&e));
 
     Grid &g = g_;
     g.nz = par.nz;
@@ -94,6 +95,13 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     fld_ = Fields{s, s + n, s + 2 * n, s + 3 * n, s + 4 * n};
     mem_ = PmlMem{s + 5 * n, s + 6 * n, s + 7 * n, s + 8 * n, s + 9 * n, s + 10 * n, s + 11 * n, s + 12 * n};
     adj_ = Fields{s + 13 * n, s + 14 * n, s + 15 * n, s + 16 * n, s + 17 * n};
+    state2_ = dalloc<float>(9 * n);
+    fld2_ = Fields{state2_, state2_ + n, state2_ + 2 * n, state2_ + 3 * n, state2_ + 4 * n};
+    mem2_ = mem_;  // velocity-side memory variables are updated in place; stress-side ones are double-buffered
+    mem2_.dvz_dz = state2_ + 5 * n;
+    mem2_.dvz_dx = state2_ + 6 * n;
+    mem2_.dvx_dz = state2_ + 7 * n;
+    mem2_.dvx_dx = state2_ + 8 * n;
     media_ = dalloc<float>(5 * n);
     HIP_OK(hipMemset(media_, 0, 5 * n * sizeof(float)));
     md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n};
@@ -148,6 +156,32 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         }
         rec_idx_ = dalloc<int>(idx.size());
         HIP_OK(hipMemcpy(rec_idx_, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        // receivers grouped by owning tile of the fused forward kernel (CSR per shot)
+        int TZ = 1, TX = 1;
+        fwd_fused_tile_shape(&TZ, &TX);
+        const int gx = (g.nx + TX - 1) / TX, gy = (g.nzc + TZ - 1) / TZ;
+        n_tiles_ = gx * gy;
+        std::vector<int> off((size_t)ns * (n_tiles_ + 1), 0), cell(idx.size()), rid(idx.size());
+        for (int i = 0; i < ns; i++) {
+            const Shot &sh = survey_.shots[i];
+            if (!sh.present) continue;
+            int *o = off.data() + (size_t)i * (n_tiles_ + 1);
+            auto tile_of = [&](int r) { return (sh.z_rec[r] / TZ) * gx + sh.x_rec[r] / TX; };
+            for (int r = 0; r < sh.nrec; r++) o[tile_of(r) + 1]++;
+            for (int t = 0; t < n_tiles_; t++) o[t + 1] += o[t];
+            std::vector<int> fill(o, o + n_tiles_);
+            for (int r = 0; r < sh.nrec; r++) {
+                const int k = rec_off_[i] + fill[tile_of(r)]++;
+                cell[k] = sh.z_rec[r] * g.pitch + sh.x_rec[r];
+                rid[k] = r;
+            }
+        }
+        rt_off_ = dalloc<int>(off.size());
+        rt_cell_ = dalloc<int>(cell.size());
+        rt_rec_ = dalloc<int>(rid.size());
+        HIP_OK(hipMemcpy(rt_off_, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(rt_cell_, cell.data(), cell.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(rt_rec_, rid.data(), rid.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     const size_t dlen = (size_t)std::max(1, survey_.max_nrec) * (size_t)par.nSteps;
     data_len_ = dlen;
@@ -165,6 +199,7 @@ Session::~Session() {
     if (frame_) (void)hipFree(frame_);
     if (h_io_) (void)hipHostFree(h_io_);
     for (auto &e : ev_) (void)hipEventDestroy(e);
+    for (auto &e : probe_ev_) (void)hipEventDestroy(e);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -279,6 +314,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     const float src_scale = (float)std::pow(1500.0, 2);  // utilities.cu:531
 
     fwd_ms_ = bwd_ms_ = 0.0;
+    probe_us_ = 0.0;
+    probe_calls_ = 0;
     fwd_steps_ = bwd_steps_ = 0;
     std::vector<float> h_gstf;
     if (withAdj) h_gstf.resize(nSteps);
@@ -291,6 +328,17 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const float *stf_s = stf_rows.data() + (size_t)is * nSteps;
         const float *d_obs = if_res ? observed_ett(id, nrec, st) : nullptr;
         const int comps = if_res ? 8 : 15;
+        // horizontal line of consecutive channels inside the computed region?
+        LineRec line{};
+        {
+            bool is_line = nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + nrec - 1 <= g.nx - 3;
+            for (int r = 1; r < nrec && is_line; r++) is_line = (sh.z_rec[r] == sh.z_rec[0] && sh.x_rec[r] == sh.x_rec[0] + r);
+            if (is_line) {
+                line.z = sh.z_rec[0];
+                line.x0 = sh.x_rec[0];
+                line.n = nrec;
+            }
+        }
         float *d_pr = syn_, *d_vx = syn_ + data_len_, *d_vz = syn_ + 2 * data_len_, *d_ett = syn_ + 3 * data_len_;
 
         // zero the 5 fields + 8 memory variables (libCUFD.cu:175-194); data column 0 stays 0 (:205-209)
@@ -301,15 +349,79 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         HIP_OK(hipMemsetAsync(d_ett, 0, (size_t)nrec * sizeof(float), st));
 
         // ---------------- forward time loop, libCUFD.cu:268-332 ----------------
+        const bool fuse_fwd = get_kernel_option("fwd_fuse") != 0;
+        Fields fcur = fld_;  // where the wavefield lives after the loop
         HIP_OK(hipEventRecord(ev_[0], st));
-        for (int it = 0; it <= nSteps - 2; it++) {
-            float *frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-            const float amp = src_scale * stf_s[it] * par_.dt;
-            launch_stress_fwd(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp);
-            launch_velocity_fwd(st, g, fld_, mem_, md_, pc_);
-            const size_t col = (size_t)(it + 1) * nrec;
-            launch_record(st, g, fld_, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
-            launches_ += 3;
+        if (fuse_fwd) {
+            // one launch per step, fields double-buffered (fwd_fused.hip)
+            HIP_OK(hipMemsetAsync(state2_, 0, 9 * n * sizeof(float), st));
+            // bundles: state_ = [5 fields | 4 stress psi | 4 velocity psi | 5 adjoint], state2_ = [5 fields | 4 stress psi]
+            float *FB[2] = {state_, state2_};
+            float *MB[2] = {state_ + 5 * n, state2_ + 5 * n};
+            const int remap = get_kernel_option("xcd_remap");
+            FwdFusedArgs a{};
+            a.mv = state_ + 9 * n;
+            a.media = media_;
+            a.cz = pc_.a_z;
+            a.cx = pc_.a_x;
+            a.rt_off = rt_off_ + (size_t)id * (n_tiles_ + 1);
+            a.rt_cell = rt_cell_ + rec_off_[id];
+            a.rt_rec = rt_rec_ + rec_off_[id];
+            a.n = (unsigned)n;
+            a.z_src = sh.z_src;
+            a.x_src = sh.x_src;
+            int cur = 0;
+            for (int it = 0; it <= nSteps - 2; it++) {
+                a.fo = FB[cur];
+                a.fn = FB[cur ^ 1];
+                a.mo = MB[cur];
+                a.mn = MB[cur ^ 1];
+                a.frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
+                a.src_amp = src_scale * stf_s[it] * par_.dt;
+                const size_t col = (size_t)it * nrec;  // column `it` = state at the start of step `it`
+                a.d_pr = d_pr + col;
+                a.d_vx = d_vx + col;
+                a.d_vz = d_vz + col;
+                a.d_ett = d_ett + col;
+                a.comps = it >= 1 ? comps : 0;
+                launch_fwd_fused(st, g, a, remap);
+                cur ^= 1;
+                launches_++;
+            }
+            const Fields F[2] = {fld_, fld2_};
+            fcur = F[cur];
+            const size_t col = (size_t)(nSteps - 1) * nrec;
+            launch_record(st, g, fcur, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
+            launches_++;
+        } else {
+            // line receivers and no pressure component wanted: sampled inside the stress kernel (column `it` from the
+            // state at the start of step `it`), last column by k_record; otherwise one k_record launch per step
+            const bool inl = line.n > 0 && !(comps & 1) && get_kernel_option("line_fuse") != 0;
+            for (int it = 0; it <= nSteps - 2; it++) {
+                float *frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
+                const float amp = src_scale * stf_s[it] * par_.dt;
+                LineRec lr{};
+                if (inl && it >= 1) {
+                    lr = line;
+                    const size_t c0 = (size_t)it * nrec;
+                    lr.d_vx = (comps & 2) ? d_vx + c0 : nullptr;
+                    lr.d_vz = (comps & 4) ? d_vz + c0 : nullptr;
+                    lr.d_ett = (comps & 8) ? d_ett + c0 : nullptr;
+                }
+                launch_stress_fwd(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, lr);
+                launch_velocity_fwd(st, g, fld_, mem_, md_, pc_);
+                launches_ += 2;
+                if (!inl) {
+                    const size_t col = (size_t)(it + 1) * nrec;
+                    launch_record(st, g, fld_, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
+                    launches_++;
+                }
+            }
+            if (inl) {
+                const size_t col = (size_t)(nSteps - 1) * nrec;
+                launch_record(st, g, fld_, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
+                launches_++;
+            }
         }
         HIP_OK(hipEventRecord(ev_[1], st));
         fwd_steps_ += nSteps - 1;
@@ -347,17 +459,31 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
             HIP_OK(hipEventRecord(ev_[2], st));
             const bool fuse = get_kernel_option_bwd_fuse() != 0;
+            const int probe = get_kernel_option("probe");
+            int n_probe = 0;
+            const bool inj_inl = line.n > 0 && get_kernel_option("line_fuse") != 0;
             for (int it = nSteps - 2; it >= 0; it--) {
                 float *frame_t = frame_ + (size_t)it * 5 * (size_t)g.frame_len;
                 const float amp = src_scale * stf_s[it] * par_.dt;
                 if (fuse) {
-                    launch_bwd_velocity(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
-                    launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
-                    launch_bwd_stress(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                    LineRec lr{};
+                    if (inj_inl) {
+                        lr = line;
+                        lr.res = res_ + (size_t)it * nrec;
+                    }
+                    launch_bwd_velocity(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_, lr);
+                    if (!inj_inl) launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
+                    if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0) {
+                        launch_bwd_stress(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_, probe_ev_[2 * n_probe],
+                                          probe_ev_[2 * n_probe + 1]);
+                        n_probe++;
+                    } else {
+                        launch_bwd_stress(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                    }
                     launches_ += 3;
                 } else {
-                    launch_velocity_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
-                    launch_stress_rev(st, g, fld_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                    launch_velocity_rev(st, g, fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
+                    launch_stress_rev(st, g, fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
                     launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
                     launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
                     launch_stress_adj(st, g, adj_, mem_, md_, pc_);
@@ -366,6 +492,15 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             }
             HIP_OK(hipEventRecord(ev_[3], st));
             bwd_steps_ += nSteps - 1;
+            if (n_probe > 0) {
+                HIP_OK(hipStreamSynchronize(st));
+                for (int k = 0; k < n_probe; k++) {
+                    float ms = 0.f;
+                    HIP_OK(hipEventElapsedTime(&ms, probe_ev_[2 * k], probe_ev_[2 * k + 1]));
+                    probe_us_ += 1e3 * ms;
+                    probe_calls_++;
+                }
+            }
             if (grad_stf) {
                 HIP_OK(hipMemcpyAsync(h_gstf.data(), stf_grad_, (size_t)nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
                 HIP_OK(hipStreamSynchronize(st));
@@ -415,6 +550,8 @@ void Session::stats(sepfwi_stats *out) const {
     out->bwd_steps = bwd_steps_;
     out->launches = launches_;
     out->device_bytes = device_bytes_;
+    out->probe_kernel_us = probe_calls_ ? probe_us_ / (double)probe_calls_ : 0.0;
+    out->probe_calls = probe_calls_;
     // one forward pass = N_c*(nSteps-1); fwd+adj = 3x (forward, reconstruction, adjoint)
     out->cell_updates = (double)out->n_c * ((double)fwd_steps_ + 2.0 * (double)bwd_steps_);
 }

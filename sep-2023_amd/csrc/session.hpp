@@ -54,10 +54,19 @@ class Session {
     std::mutex mu_;
     hipStream_t own_stream_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kProbePairs = 64;
+    hipEvent_t probe_ev_[2 * kProbePairs] = {};
+    double probe_us_ = 0.0;
+    long long probe_calls_ = 0;
     std::vector<void *> allocs_;
     long long device_bytes_ = 0;
 
     size_t cells_ = 0, data_len_ = 0;
+    float *state2_ = nullptr;  // second copy of the 5 fields + 4 stress-side memory variables (fused forward)
+    int *rt_off_ = nullptr, *rt_cell_ = nullptr, *rt_rec_ = nullptr;
+    int n_tiles_ = 0;
+    Fields fld2_{};
+    PmlMem mem2_{};
     float *state_ = nullptr, *media_ = nullptr, *acc_buf_ = nullptr, *in_stage_ = nullptr, *grad_stage_ = nullptr;
     float *frame_ = nullptr, *syn_ = nullptr, *res_ = nullptr, *xpose_ = nullptr, *stf_grad_ = nullptr, *h_io_ = nullptr;
     double *scal_ = nullptr;
