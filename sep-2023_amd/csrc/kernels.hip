@@ -37,11 +37,12 @@ namespace {
 constexpr int BX = 64;              // threads along x  (one wave)
 constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
 
-int g_opt_bz = 2;                   // waves (rows) per block
+int g_opt_bz = 1;                   // waves (rows) per block
 int g_opt_xcd_remap = 1;            // 1: each XCD gets a contiguous band of tiles
-int g_opt_bwd_fuse = 1;             // 1: two fused kernels per backward step instead of four
-int g_opt_fwd_fuse = 0;             // 1: one fused kernel per forward step (fwd_fused.hip)
+int g_opt_bwd_fuse = 2;             // backward step: 0 four kernels, 1 {vel,vel}/{stress,stress} pairs, 2 {vel,adj stress}/{stress,adj vel} pairs
+int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip)
 int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
+int g_opt_march_waves = 1280;       // target number of waves of the z-marching forward kernel
 int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
 struct Cell {
@@ -280,9 +281,11 @@ __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, 
         }
         f.vx[i] = vs;
     }
-    const float bb = md.byc_b[i];
-    if (px) m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
-    if (pz) m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
+    if (px || pz) {  // the buoyancies are only needed inside the layers: keep their loads out of the interior
+        const float bb = md.byc_b[i];
+        if (px) m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
+        if (pz) m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
+    }
 
     // vz
     const float dszz_dz = -dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
@@ -293,9 +296,11 @@ __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, 
     if (px) upz += pc.a_xh[x] * -dminus(m.dvz_dx[i - 2], m.dvz_dx[i - 1], m.dvz_dx[i], m.dvz_dx[i + 1], g.rdx);
     const float vz = f.vz[i] + upz;
     f.vz[i] = vz;
-    const float ba = md.byc_a[i];
-    if (px) m.dsxz_dx[i] = pc.b_x[x] * m.dsxz_dx[i] + ba * vz * g.dt;
-    if (pz) m.dszz_dz[i] = pc.b_zh[z] * m.dszz_dz[i] + ba * vz * g.dt;
+    if (px || pz) {
+        const float ba = md.byc_a[i];
+        if (px) m.dsxz_dx[i] = pc.b_x[x] * m.dsxz_dx[i] + ba * vz * g.dt;
+        if (pz) m.dszz_dz[i] = pc.b_zh[z] * m.dszz_dz[i] + ba * vz * g.dt;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,8 +318,6 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
     const bool px = (x < g.nPml || x > g.nx - g.nPml - 1);
     const bool wz = (z < g.nPml + 2 || z > g.nzc - g.nPml - 3);  // psi needed by stencils centred in the strip
     const bool wx = (x < g.nPml + 2 || x > g.nx - g.nPml - 3);
-    const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
-    const float l2m = lam + 2.0f * mu;
     const float ba = md.byc_a[i], bb = md.byc_b[i];
 
     // sxz
@@ -325,8 +328,11 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
     if (pz) us += pc.a_z[z] * -dplus(m.dsxz_dz[i - P], m.dsxz_dz[i], m.dsxz_dz[i + P], m.dsxz_dz[i + 2 * P], g.rdz);
     const float sxz = f.sxz[i] + us;
     f.sxz[i] = sxz;
-    if (wx) m.dvz_dx[i] = pc.b_xh[x] * m.dvz_dx[i] + sxz * amu * g.dt;
-    if (wz) m.dvx_dz[i] = pc.b_zh[z] * m.dvx_dz[i] + sxz * amu * g.dt;
+    if (wx || wz) {  // lambda, mu, ave_mu only feed the memory variables, which only exist near the layers
+        const float amu = md.ave_mu[i];
+        if (wx) m.dvz_dx[i] = pc.b_xh[x] * m.dvz_dx[i] + sxz * amu * g.dt;
+        if (wz) m.dvx_dz[i] = pc.b_zh[z] * m.dvx_dz[i] + sxz * amu * g.dt;
+    }
 
     // sxx, szz
     const float dvx_dx = -dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
@@ -339,8 +345,12 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
     const float szz = f.szz[i] + uz;
     f.sxx[i] = sxx;
     f.szz[i] = szz;
-    if (wx) m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
-    if (wz) m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+    if (wx || wz) {
+        const float lam = md.lam[i], mu = md.mu[i];
+        const float l2m = lam + 2.0f * mu;
+        if (wx) m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
+        if (wz) m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,6 +397,35 @@ __global__ __launch_bounds__(MAXT) void k_bwd_stress(Grid g, Fields f, PmlMem m,
     const Cell c = my_cell(g);
     stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
     stress_adj_body(g, c, adj, m, md, pc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward step, second pairing (option "bwd_fuse" = 2, default): the adjoint kernels need the OPPOSITE
+// coefficient set of the reverse-time kernels of the same field type (adjoint stress uses the buoyancies,
+// adjoint velocity uses lambda/mu/ave_mu: el_stress_adj.cu:63-96, el_velocity_adj.cu:69-93).  Pairing
+//   k_bwd_a = reverse-time VELOCITY (+ rho imaging, frame restore)  +  adjoint STRESS of the PREVIOUS step
+//   k_bwd_b = source_grad + reverse-time STRESS (+ lambda/mu imaging, frame restore) + adjoint VELOCITY + injection
+// lets each kernel read one coefficient set only (8 B and 12 B per cell instead of 20 B + 20 B).  Legal
+// because the adjoint stress of step t+1 is only consumed by (i) source_grad, (ii) the lambda/mu imaging and
+// (iii) the adjoint velocity of step t -- all in k_bwd_b of step t, which runs after k_bwd_a of step t; the rho
+// imaging in k_bwd_a reads the adjoint velocity, which the adjoint stress does not modify.  The adjoint stress
+// of the very last step (t = 0) is never consumed and is not computed.  Order of operations on every array is
+// the reference's (Src/libCUFD.cu:545-631).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
+                                                const float *__restrict__ frame_t, Fields adj, ImgAcc acc) {
+    const Cell c = my_cell(g);
+    velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+    stress_adj_body(g, c, adj, m, md, pc);
+}
+__global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
+                                                int z_src, int x_src, float src_amp, float src_rxz,
+                                                float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
+    const Cell c = my_cell(g);
+    // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
+    if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
+    stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+    velocity_adj_body(g, c, adj, m, md, pc, lr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -588,6 +627,7 @@ int get_kernel_option(const char *name) {
     if (n == "fwd_fuse") return g_opt_fwd_fuse;
     if (n == "line_fuse") return g_opt_line_fuse;
     if (n == "probe") return g_opt_probe;
+    if (n == "march_waves") return g_opt_march_waves;
     return -1;
 }
 
@@ -595,10 +635,11 @@ int set_kernel_option(const char *name, int value) {
     const std::string n(name ? name : "");
     if (n == "bz" && value >= 1 && value <= 16) { g_opt_bz = value; return 0; }
     if (n == "xcd_remap") { g_opt_xcd_remap = value ? 1 : 0; return 0; }
-    if (n == "bwd_fuse") { g_opt_bwd_fuse = value ? 1 : 0; return 0; }
-    if (n == "fwd_fuse") { g_opt_fwd_fuse = value ? 1 : 0; return 0; }
+    if (n == "bwd_fuse" && value >= 0 && value <= 2) { g_opt_bwd_fuse = value; return 0; }
+    if (n == "fwd_fuse" && value >= 0 && value <= 2) { g_opt_fwd_fuse = value; return 0; }
     if (n == "line_fuse") { g_opt_line_fuse = value ? 1 : 0; return 0; }
     if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
+    if (n == "march_waves" && value >= 1) { g_opt_march_waves = value; return 0; }
     return -1;
 }
 
@@ -664,6 +705,24 @@ void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media
                               x_src, src_amp, adj, acc);
     else
         hipLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
+}
+
+void launch_bwd_a(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
+                  ImgAcc acc) {
+    const Grid g = tiled(g0);
+    hipLaunchKernelGGL(k_bwd_a, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, adj, acc);
+}
+
+void launch_bwd_b(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
+                  int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
+                  hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const Grid g = tiled(g0);
+    if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
+        hipExtLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, f, m, md, pc, frame_t, z_src, x_src,
+                              src_amp, src_rxz, stf_grad_it, adj, acc, lr);
+    else
+        hipLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, src_rxz,
+                           stf_grad_it, adj, acc, lr);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

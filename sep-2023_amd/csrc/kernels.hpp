@@ -20,11 +20,17 @@ void launch_bwd_velocity(hipStream_t st, const Grid &g, Fields f, PmlMem m, Medi
 void launch_bwd_stress(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
                        int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start = nullptr,
                        hipEvent_t ev_stop = nullptr);
+void launch_bwd_a(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
+                  ImgAcc acc);
+void launch_bwd_b(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
+                  int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
+                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int get_kernel_option_bwd_fuse();
 int get_kernel_option(const char *name);
 // fused forward step (fwd_fused.hip)
 void fwd_fused_tile_shape(int *rows, int *cols);
 void launch_fwd_fused(hipStream_t st, const Grid &g, const FwdFusedArgs &a, int xcd_remap);
+void launch_fwd_march(hipStream_t st, const Grid &g, const FwdFusedArgs &a, LineRec lr, int xcd_remap);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps);
 void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t);

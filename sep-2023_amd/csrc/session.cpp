@@ -349,16 +349,18 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         HIP_OK(hipMemsetAsync(d_ett, 0, (size_t)nrec * sizeof(float), st));
 
         // ---------------- forward time loop, libCUFD.cu:268-332 ----------------
-        const bool fuse_fwd = get_kernel_option("fwd_fuse") != 0;
+        const int fuse_fwd = get_kernel_option("fwd_fuse");
         Fields fcur = fld_;  // where the wavefield lives after the loop
         HIP_OK(hipEventRecord(ev_[0], st));
         if (fuse_fwd) {
-            // one launch per step, fields double-buffered (fwd_fused.hip)
+            // one launch per step, fields double-buffered: 1 = LDS-tiled (fwd_fused.hip), 2 = z-marching (fwd_march.hip)
             HIP_OK(hipMemsetAsync(state2_, 0, 9 * n * sizeof(float), st));
             // bundles: state_ = [5 fields | 4 stress psi | 4 velocity psi | 5 adjoint], state2_ = [5 fields | 4 stress psi]
             float *FB[2] = {state_, state2_};
             float *MB[2] = {state_ + 5 * n, state2_ + 5 * n};
             const int remap = get_kernel_option("xcd_remap");
+            const bool march = (fuse_fwd == 2);
+            const bool inl = march && line.n > 0 && !(comps & 1) && get_kernel_option("line_fuse") != 0;
             FwdFusedArgs a{};
             a.mv = state_ + 9 * n;
             a.media = media_;
@@ -370,6 +372,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             a.n = (unsigned)n;
             a.z_src = sh.z_src;
             a.x_src = sh.x_src;
+            const Fields F[2] = {fld_, fld2_};
             int cur = 0;
             for (int it = 0; it <= nSteps - 2; it++) {
                 a.fo = FB[cur];
@@ -379,20 +382,37 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                 a.frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
                 a.src_amp = src_scale * stf_s[it] * par_.dt;
                 const size_t col = (size_t)it * nrec;  // column `it` = state at the start of step `it`
-                a.d_pr = d_pr + col;
-                a.d_vx = d_vx + col;
-                a.d_vz = d_vz + col;
-                a.d_ett = d_ett + col;
-                a.comps = it >= 1 ? comps : 0;
-                launch_fwd_fused(st, g, a, remap);
+                if (!march) {
+                    a.d_pr = d_pr + col;
+                    a.d_vx = d_vx + col;
+                    a.d_vz = d_vz + col;
+                    a.d_ett = d_ett + col;
+                    a.comps = it >= 1 ? comps : 0;
+                    launch_fwd_fused(st, g, a, remap);
+                } else {
+                    LineRec lr{};
+                    if (inl && it >= 1) {
+                        lr = line;
+                        lr.d_vx = (comps & 2) ? d_vx + col : nullptr;
+                        lr.d_vz = (comps & 4) ? d_vz + col : nullptr;
+                        lr.d_ett = (comps & 8) ? d_ett + col : nullptr;
+                    }
+                    launch_fwd_march(st, g, a, lr, remap);
+                    if (!inl) {  // general receivers: sample the new state into column it+1 (as the two-kernel path)
+                        const size_t c1 = (size_t)(it + 1) * nrec;
+                        launch_record(st, g, F[cur ^ 1], nrec, rec, d_pr + c1, d_vx + c1, d_vz + c1, d_ett + c1, comps);
+                        launches_++;
+                    }
+                }
                 cur ^= 1;
                 launches_++;
             }
-            const Fields F[2] = {fld_, fld2_};
             fcur = F[cur];
-            const size_t col = (size_t)(nSteps - 1) * nrec;
-            launch_record(st, g, fcur, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
-            launches_++;
+            if (!march || inl) {
+                const size_t col = (size_t)(nSteps - 1) * nrec;
+                launch_record(st, g, fcur, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
+                launches_++;
+            }
         } else {
             // line receivers and no pressure component wanted: sampled inside the stress kernel (column `it` from the
             // state at the start of step `it`), last column by k_record; otherwise one k_record launch per step
@@ -458,14 +478,31 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             HIP_OK(hipMemsetAsync(state_ + 5 * n, 0, 13 * n * sizeof(float), st));
             HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
             HIP_OK(hipEventRecord(ev_[2], st));
-            const bool fuse = get_kernel_option_bwd_fuse() != 0;
+            const int fuse = get_kernel_option_bwd_fuse();
             const int probe = get_kernel_option("probe");
             int n_probe = 0;
             const bool inj_inl = line.n > 0 && get_kernel_option("line_fuse") != 0;
             for (int it = nSteps - 2; it >= 0; it--) {
                 float *frame_t = frame_ + (size_t)it * 5 * (size_t)g.frame_len;
                 const float amp = src_scale * stf_s[it] * par_.dt;
-                if (fuse) {
+                if (fuse == 2) {
+                    LineRec lr{};
+                    if (inj_inl) {
+                        lr = line;
+                        lr.res = res_ + (size_t)it * nrec;
+                    }
+                    launch_bwd_a(st, g, fcur, mem_, md_, pc_, frame_t, adj_, acc_);
+                    if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0) {
+                        launch_bwd_b(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, stf_grad_ + it, adj_,
+                                     acc_, lr, probe_ev_[2 * n_probe], probe_ev_[2 * n_probe + 1]);
+                        n_probe++;
+                    } else {
+                        launch_bwd_b(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, stf_grad_ + it, adj_,
+                                     acc_, lr);
+                    }
+                    if (!inj_inl) launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
+                    launches_ += inj_inl ? 2 : 3;
+                } else if (fuse == 1) {
                     LineRec lr{};
                     if (inj_inl) {
                         lr = line;
