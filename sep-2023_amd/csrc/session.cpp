@@ -327,7 +327,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const int *rec = rec_idx_ + rec_off_[id];
         const float *stf_s = stf_rows.data() + (size_t)is * nSteps;
         const float *d_obs = if_res ? observed_ett(id, nrec, st) : nullptr;
-        const int comps = if_res ? 8 : 15;
+        const bool scratch = withAdj && !par_.scratch_dir_name.empty();  // libCUFD.cu:732-752
+        const int comps = if_res ? (scratch ? 9 : 8) : 15;
         // horizontal line of consecutive channels inside the computed region?
         LineRec line{};
         {
@@ -469,6 +470,41 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
             launch_residual(st, d_obs, d_ett, res_, nrec, (long long)nrec * nSteps, scal_);
             launches_++;
+            if (scratch) {
+                // optional scratch dumps of the PRESSURE component, [nrec][nSteps] float32 (libCUFD.cu:732-745):
+                // Syn_Shot{id}.bin, CondObs_Shot{id}.bin (observed data, unconditioned here as there) and
+                // Residual_Shot{id}.bin = obs - syn with the first time sample zeroed (gpuMinus, utilities.cu:154-167)
+                const size_t cnt = (size_t)nrec * nSteps;
+                launch_transpose(st, d_pr, xpose_, nSteps, nrec);
+                HIP_OK(hipMemcpyAsync(h_io_, xpose_, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                std::vector<float> obs_pr(cnt);
+                {
+                    const std::string fn = shot_file(par_, 0, id);
+                    FILE *fp = fopen(fn.c_str(), "rb");
+                    if (!fp) throw IoError("cannot read observed data '" + fn + "'");
+                    const size_t got = fread(obs_pr.data(), sizeof(float), cnt, fp);
+                    fclose(fp);
+                    if (got != cnt) throw IoError("short read on '" + fn + "'");
+                }
+                auto dump = [&](const char *stem, const float *data) {
+                    const std::string fn = par_.scratch_dir_name + "/" + stem + std::to_string(id) + ".bin";
+                    FILE *fp = fopen(fn.c_str(), "wb");
+                    if (!fp) throw IoError("cannot write '" + fn + "'");
+                    const size_t w = fwrite(data, sizeof(float), cnt, fp);
+                    fclose(fp);
+                    if (w != cnt) throw IoError("short write on '" + fn + "'");
+                };
+                dump("Syn_Shot", h_io_);
+                dump("CondObs_Shot", obs_pr.data());
+                for (int r = 0; r < nrec; r++) {
+                    float *o = obs_pr.data() + (size_t)r * nSteps;
+                    const float *sy = h_io_ + (size_t)r * nSteps;
+                    o[0] = 0.0f;
+                    for (int t = 1; t < nSteps; t++) o[t] = o[t] - sy[t];
+                }
+                dump("Residual_Shot", obs_pr.data());
+            }
         }
 
         if (withAdj) {

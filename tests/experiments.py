@@ -102,3 +102,28 @@ def run_iterate0(exp, workdir, ngpu=1, device=None):
     g = jac(obj.x0)
     grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in fwi.named_parameters()}
     return dict(f=f, ginf=float(np.abs(g).max()), grads=grads, N=int(obj.x0.size))
+
+
+def run_lbfgs(exp, workdir, nIter=3, ngpu=1):
+    """The reference's inversion driver, unchanged in structure (Main-001-...py:126-168): SciPy L-BFGS-B with the
+    reference's options on top of PyTorchObjective.  Returns the list of misfits at the accepted iterates."""
+    from scipy import optimize
+    from sepfwi import modules as M
+    from sepfwi import utils as ft
+    from sepfwi.obj_wrapper import PyTorchObjective
+    assert exp == "001"
+    su = setup(exp, workdir)
+    (vp_t, vs_t, rho_t), (vp_i, vs_i, rho_i) = models(exp)
+    pad = lambda a: torch.tensor(ft.padding_numpy_array(a, nPml, su["nPad"]), dtype=torch.float32)
+    M.FWI_obscalc(pad(vp_t), pad(vs_t), pad(rho_t), su["Stf"], su["para_fname"])(su["Shot_ids"], ngpu=ngpu)
+    T = lambda a: torch.tensor(a, dtype=torch.float32, requires_grad=True)
+    fwi = M.FWI(T(vp_i), T(vs_i), T(rho_i), su["Stf"], su["opt"], Mask=su["Mask"])
+    obj = PyTorchObjective(fwi, lambda: fwi(su["Shot_ids"], ngpu=ngpu))
+    hist = []
+    fun, jac = obj.fun, obj.jac
+    f0 = fun(obj.x0)
+    hist.append(f0)
+    optimize.minimize(fun, obj.x0, method="L-BFGS-B", jac=jac, bounds=obj.bounds, tol=None,
+                      callback=lambda x: hist.append(obj.f),
+                      options={"gtol": 1e-16, "maxiter": nIter, "ftol": 1e-12, "maxcor": 5, "maxfun": 1500, "maxls": 6})
+    return hist

@@ -1,0 +1,65 @@
+"""BASELINE.json configs[0]: 200x200 homogeneous Vp/Vs/rho, 1 Ricker shot, 500 steps -- the reference's Numba CPU
+propagator (golden traces generated from the reference's own elasticSolver.py) against the TorchFWI-order
+propagator: the CPU oracle here (CPU test) and the HIP path (GPU test).  The two schemes execute the same operator
+sequence; amplitudes differ by the source factors 1500^2*1e7*dt vs dt/2 and the axial strain by 1/dx; their
+absorbers differ (C-PML vs sponge), so the comparison window ends before boundary effects matter.
+Receivers are scattered (not a line): on the GPU this exercises the k_record fallback."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import problems as P
+from conftest import GOLDEN
+
+TOL = 2e-3
+NT_CMP = 400
+
+
+def _setup(tmp_path):
+    from sepfwi import utils as ft
+    g = np.load(os.path.join(GOLDEN, "numba_config1.npz"))
+    n, dh, dt, nt, f0, nPml = 200, float(g["dx"]), float(g["dt"]), int(g["nt"]), float(g["f0"]), 32
+    nPad = ft.nPad_for(n, nPml)
+    d = str(tmp_path)
+    para, surv = os.path.join(d, "para.json"), os.path.join(d, "survey.json")
+    ft.paraGen(n + 2 * nPml + nPad, n + 2 * nPml, dh, dh, nt, dt, f0, nPml, nPad, para, surv, os.path.join(d, "Data"))
+    rec = np.round(g["geo_coord"] / dh).astype(int)          # (x, z) cells
+    src = np.round(g["src_coord"][0] / dh).astype(int)
+    ft.surveyGen(np.array([src[1]]), np.array([src[0]]), rec[:, 1], rec[:, 0], surv)
+    vp = np.full((n, n), float(g["vp0"]), np.float32)
+    vs = np.full((n, n), float(g["vs0"]), np.float32)
+    rho = np.full((n, n), float(g["rho0"]), np.float32)
+    pad = lambda a: torch.tensor(ft.padding_numpy_array(a, nPml, nPad))
+    vp, vs, rho = pad(vp), pad(vs), pad(rho)
+    lam, mu = (vp ** 2 - 2.0 * vs ** 2) * rho / 1e6, vs ** 2 * rho / 1e6
+    Stf = torch.tensor(ft.sourceGene(f0, nt, dt), dtype=torch.float32).repeat(1, 1)
+    fac = 1500.0 ** 2 * 1.0e7 * dt / (dt / 2.0)
+    return dict(g=g, para=para, lam=lam.contiguous(), mu=mu.contiguous(), rho=rho.contiguous(), Stf=Stf, fac=fac, dh=dh, nt=nt,
+                data=os.path.join(d, "Data"))
+
+
+def _check(c, syn):
+    g, fac, k = c["g"], c["fac"], NT_CMP
+    for name, got, ref in (("vx", syn["vx"][:, :k], g["vx"][:, :k] * fac), ("vz", syn["vz"][:, :k], g["vz"][:, :k] * fac),
+                           ("ett", syn["ett"][:, :k], g["exx"][:, :k] * c["dh"] * fac),
+                           ("pr", syn["pr"][:, 1:k + 1], 2.0 * g["pr"][:, :k] * fac)):
+        e = P.rel_l2(got, ref)
+        assert e <= TOL, (name, e)
+
+
+def test_config1_oracle_vs_reference_numba_solver(tmp_path, oracle):
+    c = _setup(tmp_path)
+    para = oracle.read_json_line(c["para"])
+    out = oracle.cufd(c["lam"].numpy(), c["mu"].numpy(), c["rho"].numpy(), c["Stf"].numpy(), 2, [0], para,
+                      oracle.read_json_line(para["survey_fname"]))["syn"][0]
+    _check(c, dict(pr=out[0], vx=out[1], vz=out[2], ett=out[3]))
+
+
+@pytest.mark.gpu
+def test_config1_hip_vs_reference_numba_solver(tmp_path, hip_ops):
+    from sepfwi import utils as ft
+    c = _setup(tmp_path)
+    hip_ops.obscalc(c["lam"], c["mu"], c["rho"], c["Stf"], 1, torch.tensor([0], dtype=torch.int32), c["para"])
+    _check(c, {k: ft.read_shot_gather(c["data"], k, 0, c["nt"]) for k in ("pr", "vx", "vz", "ett")})
