@@ -41,6 +41,7 @@ Params parse_params(const std::string &text) {
         throw std::runtime_error("parameter JSON: need nz,nx > 0, nSteps >= 2, nPoints_pml >= 2, nPad >= 0");
     if (p.nz - p.nPad - 2 * p.nPml < 6 || p.nx - 2 * p.nPml < 6)
         throw std::runtime_error("parameter JSON: physical grid (nz-nPad-2*nPml, nx-2*nPml) must be at least 6x6");
+    if (p.nz > 32767 || p.nx > 32767) throw std::runtime_error("parameter JSON: nz and nx must be below 32768");
     if (!(p.dz > 0 && p.dx > 0 && p.dt > 0)) throw std::runtime_error("parameter JSON: dz, dx, dt must be positive");
     return p;
 }

@@ -35,6 +35,7 @@ using namespace dev;
 namespace {
 
 constexpr int BX = 64;              // threads along x  (one wave)
+constexpr int OCC8 = 8;             // waves per SIMD the register allocator must leave room for (SGPRs <= 80)
 constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
 
 int g_opt_bz = 1;                   // waves (rows) per block
@@ -412,15 +413,48 @@ __global__ __launch_bounds__(MAXT) void k_bwd_stress(Grid g, Fields f, PmlMem m,
 // of the very last step (t = 0) is never consumed and is not computed.  Order of operations on every array is
 // the reference's (Src/libCUFD.cu:545-631).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
-                                                const float *__restrict__ frame_t, Fields adj, ImgAcc acc) {
+// Arrays arrive as bundles (base pointer + stride) to keep the kernel's SGPR count at or below 80, the limit for
+// 8 waves per SIMD (MI355X_MICROARCH.md "Residency"): 37 separate pointers cost 74 SGPRs on their own.
+struct BwdArgs {
+    float *fields;       // vz, vx, szz, sxx, sxz          (stride n)
+    float *mem;          // 8 C-PML memory variables       (stride n)
+    float *adj;          // adjoint vz, vx, szz, sxx, sxz  (stride n)
+    const float *media;  // lam, mu, ave_mu, byc_a, byc_b  (stride n)
+    float *acc;          // lam, mu, xz, a, b              (stride n)
+    const float *cz;     // z profiles a, b, 1/K, a_half, b_half, 1/K_half (stride nzc), then the six x profiles (stride nx)
+    size_t n;
+};
+__device__ __forceinline__ Fields fields_of(float *b, size_t n) { return Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
+__device__ __forceinline__ PmlMem mem_of(float *b, size_t n) {
+    return PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
+}
+__device__ __forceinline__ Media media_of(const float *b, size_t n) { return Media{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
+__device__ __forceinline__ ImgAcc acc_of(float *b, size_t n) { return ImgAcc{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
+__device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int nzc, int nx) {
+    return PmlCoef{cz, cz + nzc, cz + 2 * nzc, cz + 3 * nzc, cz + 4 * nzc, cz + 5 * nzc,
+                   cx, cx + nx,  cx + 2 * nx,  cx + 3 * nx,  cx + 4 * nx,  cx + 5 * nx};
+}
+
+__global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *__restrict__ frame_t) {
+    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    const PmlMem m = mem_of(b.mem, b.n);
+    const Media md = media_of(b.media, b.n);
+    const ImgAcc acc = acc_of(b.acc, b.n);
+    const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
     velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
     stress_adj_body(g, c, adj, m, md, pc);
 }
-__global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
-                                                int z_src, int x_src, float src_amp, float src_rxz,
-                                                float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
+__global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__restrict__ frame_t, int zx_src /* z<<16 | x */,
+                                                float src_amp, float src_rxz, float *__restrict__ stf_grad_it,
+                                                int lr_zx /* z<<16 | x0 */, int lr_n, const float *__restrict__ lr_res) {
+    const int z_src = zx_src >> 16, x_src = zx_src & 0xffff;
+    const LineRec lr{lr_zx >> 16, lr_zx & 0xffff, lr_n, nullptr, nullptr, nullptr, lr_res};
+    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    const PmlMem m = mem_of(b.mem, b.n);
+    const Media md = media_of(b.media, b.n);
+    const ImgAcc acc = acc_of(b.acc, b.n);
+    const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
     // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
     if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
@@ -710,19 +744,21 @@ void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media
 void launch_bwd_a(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
                   ImgAcc acc) {
     const Grid g = tiled(g0);
-    hipLaunchKernelGGL(k_bwd_a, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, adj, acc);
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
+    hipLaunchKernelGGL(k_bwd_a, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
 
 void launch_bwd_b(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
                   int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
                   hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0);
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
-        hipExtLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, f, m, md, pc, frame_t, z_src, x_src,
-                              src_amp, src_rxz, stf_grad_it, adj, acc, lr);
+        hipExtLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
+                              src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
     else
-        hipLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, src_rxz,
-                           stf_grad_it, adj, acc, lr);
+        hipLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
+                           stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

@@ -129,7 +129,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
             hx[i] = a[i]; hx[nx + i] = b[i]; hx[2 * nx + i] = 1.0f / K[i];
             hx[3 * nx + i] = ah[i]; hx[4 * nx + i] = bh[i]; hx[5 * nx + i] = 1.0f / Kh[i];
         }
-        float *dz_ = dalloc<float>(hz.size()), *dx_ = dalloc<float>(hx.size());
+        float *dz_ = dalloc<float>(hz.size() + hx.size()), *dx_ = dz_ + hz.size();  // contiguous: kernels may address x profiles as z base + 6*nzc
         HIP_OK(hipMemcpy(dz_, hz.data(), hz.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(dx_, hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice));
         pc_ = PmlCoef{dz_, dz_ + nzc, dz_ + 2 * nzc, dz_ + 3 * nzc, dz_ + 4 * nzc, dz_ + 5 * nzc,
