@@ -32,11 +32,12 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_UPDATE_FWDADJ = 184.0 / 3.0   # 60 B fwd + 124 B bwd per cell per step = 61.33 B / cell-update
 BYTES_FWD = 60.0
-# Dominant kernel of the sweep: k_bwd_stress (reverse-time stress + lambda/mu imaging + adjoint stress).  Of the
-# 124 algorithmic bytes per cell of a backward step it owns the arrays it read-modify-writes and the
-# coefficients only it needs: szz,sxx,sxz r/w 24 + adjoint szz,sxx,sxz r/w 24 + lambda,mu,ave_mu 12 + grad lambda,mu
-# r/w 16 = 76 B per cell per launch (k_bwd_velocity owns the other 48 B); DESIGN.md "Kernels and rooflines".
-BYTES_K_BWD_STRESS = 76.0
+# Dominant kernel of the sweep: k_bwd_b (source_grad + reverse-time stress + lambda/mu imaging + adjoint velocity +
+# residual injection).  Of the 124 algorithmic bytes per cell of a backward step it owns the arrays it
+# read-modify-writes and the coefficients / gradients only it needs: szz,sxx,sxz r/w 24 + adjoint vz,vx r/w 16 +
+# lambda,mu,ave_mu 12 + grad lambda,mu r/w 16 = 68 B per cell per launch (k_bwd_a owns the other 56 B: vz,vx r/w 16 +
+# adjoint szz,sxx,sxz r/w 24 + byc_a,byc_b 8 + grad rho r/w 8); DESIGN.md "Kernels and rooflines".
+BYTES_K_BWD_STRESS = 68.0
 
 
 def marmousi_style(nz, nx, seed=2023):
@@ -160,7 +161,7 @@ def main():
             return fwi_ops.backward(lam, mu, den, Stf, world, ids, pb["para_fname"])
 
         from sepfwi import _native
-        _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_stress launch
+        _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_b launch
         for w in range(W):
             step(w % per_rank_shots)
         torch.cuda.synchronize()
@@ -197,11 +198,11 @@ def main():
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
             if os.path.exists(tf) and args.nz == 1000 and args.nx == 2000:
-                traffic = json.load(open(tf)).get("k_bwd_stress_bytes_per_launch")
+                traffic = json.load(open(tf)).get("k_bwd_b_bytes_per_launch")
             if args.mode == "fwdadj" and probe_n > 0:
                 per_step_us = probe_us / probe_n
                 ach = pb["n_c"] * BYTES_K_BWD_STRESS / (per_step_us * 1e-6) / 1e9
-                kern = "k_bwd_stress (%d launches sampled with HIP events in the timed region)" % probe_n
+                kern = "k_bwd_b (%d launches sampled with HIP events in the timed region)" % probe_n
             elif args.mode == "fwdadj":
                 per_step_us = bwd_ms * 1e3 / nst
                 ach = pb["n_c"] * 124.0 / (per_step_us * 1e-6) / 1e9

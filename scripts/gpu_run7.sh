@@ -6,7 +6,7 @@ export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 ( timeout 300 python __graft_entry__.py smoke ) > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 ( time timeout 900 python bench.py --steps 2 --warmup 1 ) > gpurun_out/bench_full.log 2>&1; tail -4 gpurun_out/bench_full.log
 cd /tmp
-rm -rf $R/gpurun_out/prof_r01; 
+rm -rf $R/gpurun_out/prof_r01;
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01/trace -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/prof_r01_trace.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_r01/pmc_fetch -- python $R/bench.py --steps 1 --warmup 0 --nsteps 400 --no-cpu-baseline > $R/gpurun_out/prof_r01_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/prof_r01/pmc_write -- python $R/bench.py --steps 1 --warmup 0 --nsteps 400 --no-cpu-baseline > $R/gpurun_out/prof_r01_write.log 2>&1
