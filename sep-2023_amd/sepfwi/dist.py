@@ -47,7 +47,10 @@ def allreduce_gradients(misfit, gL, gM, gD):
     n = gL.numel()
     dev = gL.device
     backend = td.get_backend()
-    use_dev = dev if (backend != "nccl" or dev.type == "cuda") else torch.device("cuda", local_device_index())
+    if backend == "nccl":     # RCCL reduces device buffers
+        use_dev = dev if dev.type == "cuda" else torch.device("cuda", local_device_index())
+    else:                     # gloo (CPU tests, or several ranks sharing one GPU): reduce on the host
+        use_dev = torch.device("cpu")
     fused = torch.empty(3 * n + 1, dtype=torch.float32, device=use_dev)
     fused[0:n] = gL.reshape(-1).to(use_dev)
     fused[n:2 * n] = gM.reshape(-1).to(use_dev)
