@@ -24,15 +24,16 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--nz", type=int, default=1000)
     ap.add_argument("--nx", type=int, default=2000)
+    ap.add_argument("--shots", type=int, default=2)
     a = ap.parse_args()
     L = _native.lib()
     dev = torch.device("cuda", 0)
     work = tempfile.mkdtemp(prefix="sepfwi_ab_")
     try:
-        pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, 1)
+        pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, a.shots)
         lt, mt, dt_ = [t.to(dev) for t in pb["lame_true"]]
         lam, mu, den = [t.to(dev) for t in pb["lame_init"]]
-        ids = torch.tensor([0], dtype=torch.int32)
+        ids = torch.arange(a.shots, dtype=torch.int32)
         fwi_ops._cufd(2, 0, lt, mt, dt_, pb["Stf"], ids, pb["para_fname"])
         res = {v: [] for v in a.variants}
         ref = None

@@ -44,6 +44,7 @@ int g_opt_bwd_fuse = 2;             // backward step: 0 four kernels, 1 {vel,vel
 int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip)
 int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
 int g_opt_march_waves = 1280;       // target number of waves of the z-marching forward kernel
+int g_opt_pair_fwd = 1;             // 1: forward passes of two shots run concurrently on two streams
 int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
 struct Cell {
@@ -662,6 +663,7 @@ int get_kernel_option(const char *name) {
     if (n == "line_fuse") return g_opt_line_fuse;
     if (n == "probe") return g_opt_probe;
     if (n == "march_waves") return g_opt_march_waves;
+    if (n == "pair_fwd") return g_opt_pair_fwd;
     return -1;
 }
 
@@ -674,6 +676,7 @@ int set_kernel_option(const char *name, int value) {
     if (n == "line_fuse") { g_opt_line_fuse = value ? 1 : 0; return 0; }
     if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
     if (n == "march_waves" && value >= 1) { g_opt_march_waves = value; return 0; }
+    if (n == "pair_fwd") { g_opt_pair_fwd = value ? 1 : 0; return 0; }
     return -1;
 }
 

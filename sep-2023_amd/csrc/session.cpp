@@ -194,6 +194,12 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
 Session::~Session() {
     (void)hipSetDevice(gpu_id_);
     (void)hipDeviceSynchronize();
+    if (lane2_state_) (void)hipFree(lane2_state_);
+    if (frame2_) (void)hipFree(frame2_);
+    if (syn2_) (void)hipFree(syn2_);
+    if (res2_) (void)hipFree(res2_);
+    if (stream2_) (void)hipStreamDestroy(stream2_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (auto &kv : obs_) (void)hipFree(kv.second.d_ett);
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
@@ -201,6 +207,26 @@ Session::~Session() {
     for (auto &e : ev_) (void)hipEventDestroy(e);
     for (auto &e : probe_ev_) (void)hipEventDestroy(e);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+// Second lane of forward state (fields, memory variables, boundary frames, seismograms, residual) and its stream.
+void Session::ensure_lane2(bool with_frames) {
+    const size_t n = cells_;
+    if (!stream2_) {
+        HIP_OK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
+    if (!lane2_state_) {
+        HIP_OK(hipMalloc((void **)&lane2_state_, 13 * n * sizeof(float)));
+        HIP_OK(hipMalloc((void **)&syn2_, 4 * data_len_ * sizeof(float)));
+        HIP_OK(hipMalloc((void **)&res2_, data_len_ * sizeof(float)));
+        device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
+    }
+    if (with_frames && !frame2_) {
+        const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
+        HIP_OK(hipMalloc((void **)&frame2_, fb));
+        device_bytes_ += (long long)fb;
+    }
 }
 
 void Session::drop_observed() {
@@ -320,275 +346,319 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     std::vector<float> h_gstf;
     if (withAdj) h_gstf.resize(nSteps);
 
-    for (int is = 0; is < group_size; is++) {
-        const int id = shot_ids[is];
-        const Shot &sh = survey_.shots[id];
-        const int nrec = sh.nrec;
-        const int *rec = rec_idx_ + rec_off_[id];
-        const float *stf_s = stf_rows.data() + (size_t)is * nSteps;
-        const float *d_obs = if_res ? observed_ett(id, nrec, st) : nullptr;
-        const bool scratch = withAdj && !par_.scratch_dir_name.empty();  // libCUFD.cu:732-752
-        const int comps = if_res ? (scratch ? 9 : 8) : 15;
+    // Per-shot context.  Two "lanes" of forward state exist so that the forward passes of two shots can run
+    // concurrently on two streams (their kernel-boundary gaps and tails fill each other: x1.2 on the forward
+    // loops; the two backward passes then run one after the other -- two of them together would not fit the
+    // 256 MB Infinity Cache and lose 15 %, scripts/concurrency_probe.py).
+    struct ShotCtx {
+        int is, id, nrec, comps;
+        const Shot *sh;
+        const int *rec;
+        const float *stf_s, *d_obs;
+        bool scratch;
+        LineRec line;
+        float *state;  // [5 fields | 8 memory variables] of this lane
+        Fields fld, fcur;
+        PmlMem mem;
+        float *frame, *syn, *res;
+        hipStream_t st;
+    };
+    const int fuse_fwd = get_kernel_option("fwd_fuse");
+    const bool can_pair = (fuse_fwd == 0) && get_kernel_option("pair_fwd") != 0 && group_size >= 2;
+    if (can_pair) ensure_lane2(withAdj);
+
+    auto make_ctx = [&](int is, int lane, hipStream_t lane_st) -> ShotCtx {
+        ShotCtx c{};
+        c.is = is;
+        c.id = shot_ids[is];
+        c.sh = &survey_.shots[c.id];
+        c.nrec = c.sh->nrec;
+        c.rec = rec_idx_ + rec_off_[c.id];
+        c.stf_s = stf_rows.data() + (size_t)is * nSteps;
+        c.d_obs = if_res ? observed_ett(c.id, c.nrec, st) : nullptr;
+        c.scratch = withAdj && !par_.scratch_dir_name.empty();  // libCUFD.cu:732-752
+        c.comps = if_res ? (c.scratch ? 9 : 8) : 15;
         // horizontal line of consecutive channels inside the computed region?
-        LineRec line{};
-        {
-            bool is_line = nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + nrec - 1 <= g.nx - 3;
-            for (int r = 1; r < nrec && is_line; r++) is_line = (sh.z_rec[r] == sh.z_rec[0] && sh.x_rec[r] == sh.x_rec[0] + r);
-            if (is_line) {
-                line.z = sh.z_rec[0];
-                line.x0 = sh.x_rec[0];
-                line.n = nrec;
-            }
+        const Shot &sh = *c.sh;
+        bool is_line = c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
+        for (int r = 1; r < c.nrec && is_line; r++) is_line = (sh.z_rec[r] == sh.z_rec[0] && sh.x_rec[r] == sh.x_rec[0] + r);
+        if (is_line) {
+            c.line.z = sh.z_rec[0];
+            c.line.x0 = sh.x_rec[0];
+            c.line.n = c.nrec;
         }
-        float *d_pr = syn_, *d_vx = syn_ + data_len_, *d_vz = syn_ + 2 * data_len_, *d_ett = syn_ + 3 * data_len_;
+        c.state = lane ? lane2_state_ : state_;
+        float *b = c.state;
+        c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
+        c.fcur = c.fld;
+        c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
+        c.frame = lane ? frame2_ : frame_;
+        c.syn = lane ? syn2_ : syn_;
+        c.res = lane ? res2_ : res_;
+        c.st = lane_st;
+        return c;
+    };
+    auto syn_of = [&](const ShotCtx &c, int comp) { return c.syn + (size_t)comp * data_len_; };
 
+    auto forward_init = [&](const ShotCtx &c) {
         // zero the 5 fields + 8 memory variables (libCUFD.cu:175-194); data column 0 stays 0 (:205-209)
-        HIP_OK(hipMemsetAsync(state_, 0, 13 * n * sizeof(float), st));
-        if (comps & 1) HIP_OK(hipMemsetAsync(d_pr, 0, (size_t)nrec * sizeof(float), st));
-        if (comps & 2) HIP_OK(hipMemsetAsync(d_vx, 0, (size_t)nrec * sizeof(float), st));
-        if (comps & 4) HIP_OK(hipMemsetAsync(d_vz, 0, (size_t)nrec * sizeof(float), st));
-        HIP_OK(hipMemsetAsync(d_ett, 0, (size_t)nrec * sizeof(float), st));
-
-        // ---------------- forward time loop, libCUFD.cu:268-332 ----------------
-        const int fuse_fwd = get_kernel_option("fwd_fuse");
-        Fields fcur = fld_;  // where the wavefield lives after the loop
-        HIP_OK(hipEventRecord(ev_[0], st));
-        if (fuse_fwd) {
-            // one launch per step, fields double-buffered: 1 = LDS-tiled (fwd_fused.hip), 2 = z-marching (fwd_march.hip)
-            HIP_OK(hipMemsetAsync(state2_, 0, 9 * n * sizeof(float), st));
-            // bundles: state_ = [5 fields | 4 stress psi | 4 velocity psi | 5 adjoint], state2_ = [5 fields | 4 stress psi]
-            float *FB[2] = {state_, state2_};
-            float *MB[2] = {state_ + 5 * n, state2_ + 5 * n};
-            const int remap = get_kernel_option("xcd_remap");
-            const bool march = (fuse_fwd == 2);
-            const bool inl = march && line.n > 0 && !(comps & 1) && get_kernel_option("line_fuse") != 0;
-            FwdFusedArgs a{};
-            a.mv = state_ + 9 * n;
-            a.media = media_;
-            a.cz = pc_.a_z;
-            a.cx = pc_.a_x;
-            a.rt_off = rt_off_ + (size_t)id * (n_tiles_ + 1);
-            a.rt_cell = rt_cell_ + rec_off_[id];
-            a.rt_rec = rt_rec_ + rec_off_[id];
-            a.n = (unsigned)n;
-            a.z_src = sh.z_src;
-            a.x_src = sh.x_src;
-            const Fields F[2] = {fld_, fld2_};
-            int cur = 0;
-            for (int it = 0; it <= nSteps - 2; it++) {
-                a.fo = FB[cur];
-                a.fn = FB[cur ^ 1];
-                a.mo = MB[cur];
-                a.mn = MB[cur ^ 1];
-                a.frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-                a.src_amp = src_scale * stf_s[it] * par_.dt;
-                const size_t col = (size_t)it * nrec;  // column `it` = state at the start of step `it`
-                if (!march) {
-                    a.d_pr = d_pr + col;
-                    a.d_vx = d_vx + col;
-                    a.d_vz = d_vz + col;
-                    a.d_ett = d_ett + col;
-                    a.comps = it >= 1 ? comps : 0;
-                    launch_fwd_fused(st, g, a, remap);
-                } else {
-                    LineRec lr{};
-                    if (inl && it >= 1) {
-                        lr = line;
-                        lr.d_vx = (comps & 2) ? d_vx + col : nullptr;
-                        lr.d_vz = (comps & 4) ? d_vz + col : nullptr;
-                        lr.d_ett = (comps & 8) ? d_ett + col : nullptr;
-                    }
-                    launch_fwd_march(st, g, a, lr, remap);
-                    if (!inl) {  // general receivers: sample the new state into column it+1 (as the two-kernel path)
-                        const size_t c1 = (size_t)(it + 1) * nrec;
-                        launch_record(st, g, F[cur ^ 1], nrec, rec, d_pr + c1, d_vx + c1, d_vz + c1, d_ett + c1, comps);
-                        launches_++;
-                    }
-                }
-                cur ^= 1;
-                launches_++;
-            }
-            fcur = F[cur];
-            if (!march || inl) {
-                const size_t col = (size_t)(nSteps - 1) * nrec;
-                launch_record(st, g, fcur, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
-                launches_++;
-            }
-        } else {
-            // line receivers and no pressure component wanted: sampled inside the stress kernel (column `it` from the
-            // state at the start of step `it`), last column by k_record; otherwise one k_record launch per step
-            const bool inl = line.n > 0 && !(comps & 1) && get_kernel_option("line_fuse") != 0;
-            for (int it = 0; it <= nSteps - 2; it++) {
-                float *frame_t = withAdj ? frame_ + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-                const float amp = src_scale * stf_s[it] * par_.dt;
+        HIP_OK(hipMemsetAsync(c.state, 0, 13 * n * sizeof(float), c.st));
+        for (int k = 0; k < 4; k++)
+            if ((c.comps >> k) & 1) HIP_OK(hipMemsetAsync(syn_of(c, k), 0, (size_t)c.nrec * sizeof(float), c.st));
+    };
+    // one forward time step, two-kernel form (libCUFD.cu:268-332)
+    auto forward_step = [&](const ShotCtx &c, int it, bool inl) {
+        float *frame_t = withAdj ? c.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
+        const float amp = src_scale * c.stf_s[it] * par_.dt;
+        LineRec lr{};
+        if (inl && it >= 1) {
+            lr = c.line;
+            const size_t c0 = (size_t)it * c.nrec;
+            lr.d_vx = (c.comps & 2) ? syn_of(c, 1) + c0 : nullptr;
+            lr.d_vz = (c.comps & 4) ? syn_of(c, 2) + c0 : nullptr;
+            lr.d_ett = (c.comps & 8) ? syn_of(c, 3) + c0 : nullptr;
+        }
+        launch_stress_fwd(c.st, g, c.fld, c.mem, md_, pc_, frame_t, c.sh->z_src, c.sh->x_src, amp, lr);
+        launch_velocity_fwd(c.st, g, c.fld, c.mem, md_, pc_);
+        launches_ += 2;
+        if (!inl) {
+            const size_t col = (size_t)(it + 1) * c.nrec;
+            launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+            launches_++;
+        }
+    };
+    auto forward_last_column = [&](const ShotCtx &c) {
+        const size_t col = (size_t)(nSteps - 1) * c.nrec;
+        launch_record(c.st, g, c.fcur, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+        launches_++;
+    };
+    // fused single-launch forward steps (lane 0 only): 1 = LDS-tiled (fwd_fused.hip), 2 = z-marching (fwd_march.hip)
+    auto forward_fused = [&](ShotCtx &c) {
+        HIP_OK(hipMemsetAsync(state2_, 0, 9 * n * sizeof(float), c.st));
+        // bundles: state_ = [5 fields | 4 stress psi | 4 velocity psi | 5 adjoint], state2_ = [5 fields | 4 stress psi]
+        float *FB[2] = {state_, state2_};
+        float *MB[2] = {state_ + 5 * n, state2_ + 5 * n};
+        const int remap = get_kernel_option("xcd_remap");
+        const bool march = (fuse_fwd == 2);
+        const bool inl = march && c.line.n > 0 && !(c.comps & 1) && get_kernel_option("line_fuse") != 0;
+        FwdFusedArgs a{};
+        a.mv = state_ + 9 * n;
+        a.media = media_;
+        a.cz = pc_.a_z;
+        a.cx = pc_.a_x;
+        a.rt_off = rt_off_ + (size_t)c.id * (n_tiles_ + 1);
+        a.rt_cell = rt_cell_ + rec_off_[c.id];
+        a.rt_rec = rt_rec_ + rec_off_[c.id];
+        a.n = (unsigned)n;
+        a.z_src = c.sh->z_src;
+        a.x_src = c.sh->x_src;
+        const Fields F[2] = {fld_, fld2_};
+        int cur = 0;
+        for (int it = 0; it <= nSteps - 2; it++) {
+            a.fo = FB[cur];
+            a.fn = FB[cur ^ 1];
+            a.mo = MB[cur];
+            a.mn = MB[cur ^ 1];
+            a.frame_t = withAdj ? c.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
+            a.src_amp = src_scale * c.stf_s[it] * par_.dt;
+            const size_t col = (size_t)it * c.nrec;  // column `it` = state at the start of step `it`
+            if (!march) {
+                a.d_pr = syn_of(c, 0) + col;
+                a.d_vx = syn_of(c, 1) + col;
+                a.d_vz = syn_of(c, 2) + col;
+                a.d_ett = syn_of(c, 3) + col;
+                a.comps = it >= 1 ? c.comps : 0;
+                launch_fwd_fused(c.st, g, a, remap);
+            } else {
                 LineRec lr{};
                 if (inl && it >= 1) {
-                    lr = line;
-                    const size_t c0 = (size_t)it * nrec;
-                    lr.d_vx = (comps & 2) ? d_vx + c0 : nullptr;
-                    lr.d_vz = (comps & 4) ? d_vz + c0 : nullptr;
-                    lr.d_ett = (comps & 8) ? d_ett + c0 : nullptr;
+                    lr = c.line;
+                    lr.d_vx = (c.comps & 2) ? syn_of(c, 1) + col : nullptr;
+                    lr.d_vz = (c.comps & 4) ? syn_of(c, 2) + col : nullptr;
+                    lr.d_ett = (c.comps & 8) ? syn_of(c, 3) + col : nullptr;
                 }
-                launch_stress_fwd(st, g, fld_, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, lr);
-                launch_velocity_fwd(st, g, fld_, mem_, md_, pc_);
-                launches_ += 2;
-                if (!inl) {
-                    const size_t col = (size_t)(it + 1) * nrec;
-                    launch_record(st, g, fld_, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
+                launch_fwd_march(c.st, g, a, lr, remap);
+                if (!inl) {  // general receivers: sample the new state into column it+1 (as the two-kernel path)
+                    const size_t c1 = (size_t)(it + 1) * c.nrec;
+                    launch_record(c.st, g, F[cur ^ 1], c.nrec, c.rec, syn_of(c, 0) + c1, syn_of(c, 1) + c1, syn_of(c, 2) + c1, syn_of(c, 3) + c1, c.comps);
                     launches_++;
                 }
             }
-            if (inl) {
-                const size_t col = (size_t)(nSteps - 1) * nrec;
-                launch_record(st, g, fld_, nrec, rec, d_pr + col, d_vx + col, d_vz + col, d_ett + col, comps);
-                launches_++;
+            cur ^= 1;
+            launches_++;
+        }
+        c.fcur = F[cur];
+        if (!march || inl) forward_last_column(c);
+    };
+    auto residual = [&](const ShotCtx &c) {
+        // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
+        launch_residual(c.st, c.d_obs, syn_of(c, 3), c.res, c.nrec, (long long)c.nrec * nSteps, scal_);
+        launches_++;
+    };
+    auto export_gathers = [&](const ShotCtx &c) {
+        // observe: export the four gathers as [nrec][nSteps] files (libCUFD.cu:755-769)
+        for (int k = 0; k < 4; k++) {
+            launch_transpose(st, syn_of(c, k), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
+            HIP_OK(hipMemcpyAsync(h_io_, xpose_, (size_t)c.nrec * nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            const std::string fn = shot_file(par_, k, c.id);
+            FILE *fp = fopen(fn.c_str(), "wb");
+            if (!fp) throw IoError("cannot write '" + fn + "'");  // utilities.cu:22-31
+            size_t w = fwrite(h_io_, sizeof(float), (size_t)c.nrec * nSteps, fp);
+            fclose(fp);
+            if (w != (size_t)c.nrec * nSteps) throw IoError("short write on '" + fn + "'");
+        }
+        auto oit = obs_.find(c.id);  // stale cache entry for this shot: drop, the file just changed
+        if (oit != obs_.end()) {
+            (void)hipFree(oit->second.d_ett);
+            device_bytes_ -= (long long)oit->second.bytes;
+            obs_.erase(oit);
+        }
+    };
+    auto scratch_dumps = [&](const ShotCtx &c) {
+        // optional scratch dumps of the PRESSURE component, [nrec][nSteps] float32 (libCUFD.cu:732-745):
+        // Syn_Shot{id}.bin, CondObs_Shot{id}.bin (observed data, unconditioned here as there) and
+        // Residual_Shot{id}.bin = obs - syn with the first time sample zeroed (gpuMinus, utilities.cu:154-167)
+        const size_t cnt = (size_t)c.nrec * nSteps;
+        launch_transpose(st, syn_of(c, 0), xpose_, nSteps, c.nrec);
+        HIP_OK(hipMemcpyAsync(h_io_, xpose_, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<float> obs_pr(cnt);
+        {
+            const std::string fn = shot_file(par_, 0, c.id);
+            FILE *fp = fopen(fn.c_str(), "rb");
+            if (!fp) throw IoError("cannot read observed data '" + fn + "'");
+            const size_t got = fread(obs_pr.data(), sizeof(float), cnt, fp);
+            fclose(fp);
+            if (got != cnt) throw IoError("short read on '" + fn + "'");
+        }
+        auto dump = [&](const char *stem, const float *data) {
+            const std::string fn = par_.scratch_dir_name + "/" + stem + std::to_string(c.id) + ".bin";
+            FILE *fp = fopen(fn.c_str(), "wb");
+            if (!fp) throw IoError("cannot write '" + fn + "'");
+            const size_t w = fwrite(data, sizeof(float), cnt, fp);
+            fclose(fp);
+            if (w != cnt) throw IoError("short write on '" + fn + "'");
+        };
+        dump("Syn_Shot", h_io_);
+        dump("CondObs_Shot", obs_pr.data());
+        for (int r = 0; r < c.nrec; r++) {
+            float *o = obs_pr.data() + (size_t)r * nSteps;
+            const float *sy = h_io_ + (size_t)r * nSteps;
+            o[0] = 0.0f;
+            for (int t = 1; t < nSteps; t++) o[t] = o[t] - sy[t];
+        }
+        dump("Residual_Shot", obs_pr.data());
+    };
+    // backward of one shot on the main stream (libCUFD.cu:500-675)
+    auto backward = [&](const ShotCtx &c) {
+        // adjoint fields + all eight memory variables restart from zero (:503-515); the two pre-loop
+        // adjoint launches (:520-542) act on all-zero arrays and change nothing.
+        HIP_OK(hipMemsetAsync(state_ + 5 * n, 0, 13 * n * sizeof(float), st));
+        HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
+        HIP_OK(hipEventRecord(ev_[2], st));
+        const int fuse = get_kernel_option_bwd_fuse();
+        const int probe = get_kernel_option("probe");
+        int n_probe = 0;
+        const bool inj_inl = c.line.n > 0 && get_kernel_option("line_fuse") != 0;
+        const Shot &sh = *c.sh;
+        for (int it = nSteps - 2; it >= 0; it--) {
+            float *frame_t = c.frame + (size_t)it * 5 * (size_t)g.frame_len;
+            const float amp = src_scale * c.stf_s[it] * par_.dt;
+            const float *res_t = c.res + (size_t)it * c.nrec;
+            LineRec lr{};
+            if (inj_inl) {
+                lr = c.line;
+                lr.res = res_t;
             }
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0 && fuse != 0) {
+                e0 = probe_ev_[2 * n_probe];
+                e1 = probe_ev_[2 * n_probe + 1];
+                n_probe++;
+            }
+            if (fuse == 2) {
+                launch_bwd_a(st, g, c.fcur, mem_, md_, pc_, frame_t, adj_, acc_);
+                launch_bwd_b(st, g, c.fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_, lr, e0, e1);
+                if (!inj_inl) launch_inject(st, adj_, c.nrec, c.rec, res_t);
+                launches_ += inj_inl ? 2 : 3;
+            } else if (fuse == 1) {
+                launch_bwd_velocity(st, g, c.fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_, lr);
+                if (!inj_inl) launch_inject(st, adj_, c.nrec, c.rec, res_t);
+                launch_bwd_stress(st, g, c.fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_, e0, e1);
+                launches_ += 3;
+            } else {
+                launch_velocity_rev(st, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
+                launch_stress_rev(st, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
+                launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
+                launch_inject(st, adj_, c.nrec, c.rec, res_t);
+                launch_stress_adj(st, g, adj_, mem_, md_, pc_);
+                launches_ += 5;
+            }
+        }
+        HIP_OK(hipEventRecord(ev_[3], st));
+        bwd_steps_ += nSteps - 1;
+        HIP_OK(hipStreamSynchronize(st));
+        for (int k = 0; k < n_probe; k++) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, probe_ev_[2 * k], probe_ev_[2 * k + 1]));
+            probe_us_ += 1e3 * ms;
+            probe_calls_++;
+        }
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
+        bwd_ms_ += ms;
+        if (grad_stf) {
+            HIP_OK(hipMemcpy(h_gstf.data(), stf_grad_, (size_t)nSteps * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(grad_stf + (size_t)c.is * nSteps, h_gstf.data(), (size_t)nSteps * sizeof(float), hipMemcpyDefault));
+        }
+    };
+
+    for (int is = 0; is < group_size;) {
+        const int np = (can_pair && is + 1 < group_size) ? 2 : 1;
+        ShotCtx ctx[2];
+        ctx[0] = make_ctx(is, 0, st);
+        if (np == 2) ctx[1] = make_ctx(is + 1, 1, stream2_);
+
+        // ---------------- forward time loop(s), libCUFD.cu:268-332 ----------------
+        HIP_OK(hipEventRecord(ev_[0], st));
+        if (np == 2) HIP_OK(hipStreamWaitEvent(stream2_, ev_[0], 0));  // lane 2 starts after everything queued so far
+        for (int k = 0; k < np; k++) forward_init(ctx[k]);
+        if (fuse_fwd) {
+            forward_fused(ctx[0]);
+        } else {
+            bool inl[2];
+            for (int k = 0; k < np; k++)
+                inl[k] = ctx[k].line.n > 0 && !(ctx[k].comps & 1) && get_kernel_option("line_fuse") != 0;
+            for (int it = 0; it <= nSteps - 2; it++)
+                for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
+            for (int k = 0; k < np; k++)
+                if (inl[k]) forward_last_column(ctx[k]);
+        }
+        if (if_res)
+            for (int k = 0; k < np; k++) residual(ctx[k]);
+        if (np == 2) {  // join: the main stream continues when lane 2 is done
+            HIP_OK(hipEventRecord(ev_join_, stream2_));
+            HIP_OK(hipStreamWaitEvent(st, ev_join_, 0));
         }
         HIP_OK(hipEventRecord(ev_[1], st));
-        fwd_steps_ += nSteps - 1;
-
-        if (!if_res) {
-            // observe: export the four gathers as [nrec][nSteps] files (libCUFD.cu:755-769)
-            for (int c = 0; c < 4; c++) {
-                launch_transpose(st, syn_ + (size_t)c * data_len_, xpose_, nSteps, nrec);  // [it][rec] -> [rec][it]
-                HIP_OK(hipMemcpyAsync(h_io_, xpose_, (size_t)nrec * nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
-                HIP_OK(hipStreamSynchronize(st));
-                const std::string fn = shot_file(par_, c, id);
-                FILE *fp = fopen(fn.c_str(), "wb");
-                if (!fp) throw IoError("cannot write '" + fn + "'");  // utilities.cu:22-31
-                size_t w = fwrite(h_io_, sizeof(float), (size_t)nrec * nSteps, fp);
-                fclose(fp);
-                if (w != (size_t)nrec * nSteps) throw IoError("short write on '" + fn + "'");
-            }
-            auto oit = obs_.find(id);  // stale cache entry for this shot: drop, the file just changed
-            if (oit != obs_.end()) {
-                (void)hipFree(oit->second.d_ett);
-                device_bytes_ -= (long long)oit->second.bytes;
-                obs_.erase(oit);
-            }
-        } else {
-            // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
-            launch_residual(st, d_obs, d_ett, res_, nrec, (long long)nrec * nSteps, scal_);
-            launches_++;
-            if (scratch) {
-                // optional scratch dumps of the PRESSURE component, [nrec][nSteps] float32 (libCUFD.cu:732-745):
-                // Syn_Shot{id}.bin, CondObs_Shot{id}.bin (observed data, unconditioned here as there) and
-                // Residual_Shot{id}.bin = obs - syn with the first time sample zeroed (gpuMinus, utilities.cu:154-167)
-                const size_t cnt = (size_t)nrec * nSteps;
-                launch_transpose(st, d_pr, xpose_, nSteps, nrec);
-                HIP_OK(hipMemcpyAsync(h_io_, xpose_, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
-                HIP_OK(hipStreamSynchronize(st));
-                std::vector<float> obs_pr(cnt);
-                {
-                    const std::string fn = shot_file(par_, 0, id);
-                    FILE *fp = fopen(fn.c_str(), "rb");
-                    if (!fp) throw IoError("cannot read observed data '" + fn + "'");
-                    const size_t got = fread(obs_pr.data(), sizeof(float), cnt, fp);
-                    fclose(fp);
-                    if (got != cnt) throw IoError("short read on '" + fn + "'");
-                }
-                auto dump = [&](const char *stem, const float *data) {
-                    const std::string fn = par_.scratch_dir_name + "/" + stem + std::to_string(id) + ".bin";
-                    FILE *fp = fopen(fn.c_str(), "wb");
-                    if (!fp) throw IoError("cannot write '" + fn + "'");
-                    const size_t w = fwrite(data, sizeof(float), cnt, fp);
-                    fclose(fp);
-                    if (w != cnt) throw IoError("short write on '" + fn + "'");
-                };
-                dump("Syn_Shot", h_io_);
-                dump("CondObs_Shot", obs_pr.data());
-                for (int r = 0; r < nrec; r++) {
-                    float *o = obs_pr.data() + (size_t)r * nSteps;
-                    const float *sy = h_io_ + (size_t)r * nSteps;
-                    o[0] = 0.0f;
-                    for (int t = 1; t < nSteps; t++) o[t] = o[t] - sy[t];
-                }
-                dump("Residual_Shot", obs_pr.data());
-            }
-        }
-
-        if (withAdj) {
-            // ---------------- backward, libCUFD.cu:500-675 ----------------
-            // adjoint fields + all eight memory variables restart from zero (:503-515); the two pre-loop
-            // adjoint launches (:520-542) act on all-zero arrays and change nothing.
-            HIP_OK(hipMemsetAsync(state_ + 5 * n, 0, 13 * n * sizeof(float), st));
-            HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
-            HIP_OK(hipEventRecord(ev_[2], st));
-            const int fuse = get_kernel_option_bwd_fuse();
-            const int probe = get_kernel_option("probe");
-            int n_probe = 0;
-            const bool inj_inl = line.n > 0 && get_kernel_option("line_fuse") != 0;
-            for (int it = nSteps - 2; it >= 0; it--) {
-                float *frame_t = frame_ + (size_t)it * 5 * (size_t)g.frame_len;
-                const float amp = src_scale * stf_s[it] * par_.dt;
-                if (fuse == 2) {
-                    LineRec lr{};
-                    if (inj_inl) {
-                        lr = line;
-                        lr.res = res_ + (size_t)it * nrec;
-                    }
-                    launch_bwd_a(st, g, fcur, mem_, md_, pc_, frame_t, adj_, acc_);
-                    if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0) {
-                        launch_bwd_b(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, stf_grad_ + it, adj_,
-                                     acc_, lr, probe_ev_[2 * n_probe], probe_ev_[2 * n_probe + 1]);
-                        n_probe++;
-                    } else {
-                        launch_bwd_b(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, stf_grad_ + it, adj_,
-                                     acc_, lr);
-                    }
-                    if (!inj_inl) launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
-                    launches_ += inj_inl ? 2 : 3;
-                } else if (fuse == 1) {
-                    LineRec lr{};
-                    if (inj_inl) {
-                        lr = line;
-                        lr.res = res_ + (size_t)it * nrec;
-                    }
-                    launch_bwd_velocity(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_, lr);
-                    if (!inj_inl) launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
-                    if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0) {
-                        launch_bwd_stress(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_, probe_ev_[2 * n_probe],
-                                          probe_ev_[2 * n_probe + 1]);
-                        n_probe++;
-                    } else {
-                        launch_bwd_stress(st, g, fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
-                    }
-                    launches_ += 3;
-                } else {
-                    launch_velocity_rev(st, g, fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
-                    launch_stress_rev(st, g, fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
-                    launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
-                    launch_inject(st, adj_, nrec, rec, res_ + (size_t)it * nrec);
-                    launch_stress_adj(st, g, adj_, mem_, md_, pc_);
-                    launches_ += 5;
-                }
-            }
-            HIP_OK(hipEventRecord(ev_[3], st));
-            bwd_steps_ += nSteps - 1;
-            if (n_probe > 0) {
-                HIP_OK(hipStreamSynchronize(st));
-                for (int k = 0; k < n_probe; k++) {
-                    float ms = 0.f;
-                    HIP_OK(hipEventElapsedTime(&ms, probe_ev_[2 * k], probe_ev_[2 * k + 1]));
-                    probe_us_ += 1e3 * ms;
-                    probe_calls_++;
-                }
-            }
-            if (grad_stf) {
-                HIP_OK(hipMemcpyAsync(h_gstf.data(), stf_grad_, (size_t)nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
-                HIP_OK(hipStreamSynchronize(st));
-                HIP_OK(hipMemcpy(grad_stf + (size_t)is * nSteps, h_gstf.data(), (size_t)nSteps * sizeof(float), hipMemcpyDefault));
-            }
-        }
-        // event times are read shot by shot (cheap: one sync per shot)
+        fwd_steps_ += (long long)np * (nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));
-        float ms = 0.f;
-        HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-        fwd_ms_ += ms;
-        if (withAdj) {
-            HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
-            bwd_ms_ += ms;
+        {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+            fwd_ms_ += ms;
         }
+
+        for (int k = 0; k < np; k++) {
+            if (!if_res) {
+                export_gathers(ctx[k]);
+            } else if (ctx[k].scratch) {
+                scratch_dumps(ctx[k]);
+            }
+            if (withAdj) backward(ctx[k]);
+        }
+        is += np;
     }
 
     // ---- outputs ----

@@ -38,6 +38,7 @@ class Session {
   private:
     template <class T> T *dalloc(size_t n);
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
+    void ensure_lane2(bool with_frames);
 
     struct ObsEntry {
         float *d_ett = nullptr;  // [nSteps][nrec]
@@ -62,6 +63,9 @@ class Session {
     long long device_bytes_ = 0;
 
     size_t cells_ = 0, data_len_ = 0;
+    float *lane2_state_ = nullptr, *frame2_ = nullptr, *syn2_ = nullptr, *res2_ = nullptr;  // second forward lane
+    hipStream_t stream2_ = nullptr;
+    hipEvent_t ev_join_ = nullptr;
     float *state2_ = nullptr;  // second copy of the 5 fields + 4 stress-side memory variables (fused forward)
     int *rt_off_ = nullptr, *rt_cell_ = nullptr, *rt_rec_ = nullptr;
     int n_tiles_ = 0;
