@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--nsteps", type=int, default=4000, help="time steps per shot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="fwdadj", choices=["fwdadj", "fwd"])
+    ap.add_argument("--shots-per-step", type=int, default=2,
+                    help="shots each GPU processes per step (2: the forward passes of the pair overlap on two streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,16 +140,17 @@ def main():
     from sepfwi import fwi_ops
     fwi_ops.device_override = local
     K, W = args.steps, args.warmup
-    per_rank_shots = max(K, 1)
-    n_total = world * per_rank_shots
+    spr = max(args.shots_per_step, 1)
+    per_rank_steps = max(K, 1)
+    n_total = world * per_rank_steps * spr
     workdir = tempfile.mkdtemp(prefix="sepfwi_bench_r%d_" % rank)
     try:
         pb = setup_problem(workdir, args.nz, args.nx, args.nsteps, n_total)
         lam_t, mu_t, den_t = [t.to(dev) for t in pb["lame_true"]]
         lam, mu, den = [t.to(dev) for t in pb["lame_init"]]
         Stf = pb["Stf"]
-        # shot ids: step s uses [s*world + r for r in ranks] -> every rank exactly one shot per step
-        my_ids = [s * world + rank for s in range(per_rank_shots)]
+        # shot ids: step s uses the block [s*world*spr, (s+1)*world*spr); rank r owns the r-th contiguous group of spr shots
+        my_ids = [s * world * spr + rank * spr + j for s in range(per_rank_steps) for j in range(spr)]
         # observed data for my shots (untimed set-up; each rank writes its own files, then caches them in HBM)
         from sepfwi import dist as _dist
         _cufd = fwi_ops._cufd
@@ -155,15 +158,15 @@ def main():
         del lam_t, mu_t, den_t
 
         def step(s):
-            ids = torch.tensor([s * world + r for r in range(world)], dtype=torch.int32)
+            ids = torch.arange(s * world * spr, (s + 1) * world * spr, dtype=torch.int32)
             if args.mode == "fwd":
-                return fwi_ops.forward(lam, mu, den, Stf, local, ids[rank:rank + 1], pb["para_fname"])
+                return fwi_ops.forward(lam, mu, den, Stf, local, ids[rank * spr:(rank + 1) * spr], pb["para_fname"])
             return fwi_ops.backward(lam, mu, den, Stf, world, ids, pb["para_fname"])
 
         from sepfwi import _native
         _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_b launch
         for w in range(W):
-            step(w % per_rank_shots)
+            step(w % per_rank_steps)
         torch.cuda.synchronize()
         if world > 1:
             td.barrier()
@@ -190,11 +193,11 @@ def main():
 
         passes = 3 if args.mode == "fwdadj" else 1
         updates_per_shot = passes * pb["n_c"] * (args.nsteps - 1)
-        value = world * K * updates_per_shot / el / 1e9
+        value = world * K * spr * updates_per_shot / el / 1e9
         if rank == 0:
             # roofline of the dominant kernel group, measured live with HIP events on the session stream
             # (sepfwi_stats.fwd_ms / bwd_ms): algorithmic bytes per time step / measured time per time step.
-            nst = K * (args.nsteps - 1)
+            nst = K * spr * (args.nsteps - 1)
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
             if os.path.exists(tf) and args.nz == 1000 and args.nx == 2000:
@@ -218,14 +221,14 @@ def main():
                 "ms_per_step": round(el * 1e3 / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "configs[2] shape: %dx%d model (padded %dx%d), %d time steps, %d DAS channels, "
-                                       "1 shot per GPU per step, %s" % (args.nx, args.nz, pb["nx_pad"], pb["nz_pad"], args.nsteps,
-                                                                        pb["nrec"], "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
-                           "cell_updates_per_shot": updates_per_shot, "parallelism": "shots x%d" % world},
+                                       "%d shot(s) per GPU per step, %s" % (args.nx, args.nz, pb["nx_pad"], pb["nz_pad"], args.nsteps,
+                                                                        pb["nrec"], spr, "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
+                           "cell_updates_per_shot": updates_per_shot, "shots_per_gpu_per_step": spr, "parallelism": "shots x%d" % world},
                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": kern,
                              "avg_us": round(per_step_us, 2),
                              "whole_job_frac": round(value * (BYTES_PER_UPDATE_FWDADJ if args.mode == "fwdadj" else BYTES_FWD) / world / HBM_PEAK_GBPS, 4)},
-                "fwd_ms_per_shot": round(fwd_ms / K, 2), "bwd_ms_per_shot": round(bwd_ms / K, 2),
+                "fwd_ms_per_shot": round(fwd_ms / (K * spr), 2), "bwd_ms_per_shot": round(bwd_ms / (K * spr), 2),
                 "fwd_us_per_time_step": round(fwd_ms * 1e3 / nst, 2), "bwd_us_per_time_step": round(bwd_ms * 1e3 / nst, 2),
             }
             if not args.no_cpu_baseline and world == 1:

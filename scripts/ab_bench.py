@@ -17,6 +17,9 @@ import bench
 from sepfwi import _native, fwi_ops
 
 
+DEFAULTS = dict(bz=1, xcd_remap=1, bwd_fuse=2, fwd_fuse=0, line_fuse=1, pair_fwd=1, pair_bwd=0, acc_nt=2, pipe_bwd=0, early=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("variants", nargs="+")
@@ -39,6 +42,8 @@ def main():
         ref = None
         for r in range(a.rounds + 1):
             for v in a.variants:
+                for k, val in DEFAULTS.items():   # options are sticky in the library: start every variant from the defaults
+                    _native.check(L.sepfwi_set_option(k.encode(), val))
                 for kv in v.split(","):
                     if not kv:
                         continue

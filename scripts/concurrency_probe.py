@@ -12,10 +12,11 @@ from sepfwi import fwi_ops
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 mode = sys.argv[2] if len(sys.argv) > 2 else "bwd"
 NC = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+NZ = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
 dev = torch.device("cuda", 0)
 works = [tempfile.mkdtemp(prefix="sepfwi_cc%d_" % i) for i in range(NC)]
 try:
-    pbs = [bench.setup_problem(w, 1000, 2000, nsteps, 1) for w in works]
+    pbs = [bench.setup_problem(w, NZ, 2000, nsteps, 1) for w in works]
     ids = torch.tensor([0], dtype=torch.int32)
     ins = []
     for pb in pbs:
@@ -34,7 +35,7 @@ try:
         with ThreadPoolExecutor(max_workers=NC) as ex:
             list(ex.map(run, range(NC)))
         torch.cuda.synchronize(); t_con = time.perf_counter() - t0
-        print("%s nsteps %d: %d shots sequential %.1f ms, concurrent %.1f ms  (x%.3f)" % (mode, nsteps, NC, t_seq * 1e3, t_con * 1e3, t_seq / t_con))
+        print("nz %d %s nsteps %d: %d shots sequential %.1f ms, concurrent %.1f ms  (x%.3f)" % (NZ, mode, nsteps, NC, t_seq * 1e3, t_con * 1e3, t_seq / t_con))
 finally:
     for w in works:
         shutil.rmtree(w, ignore_errors=True)

@@ -45,6 +45,10 @@ int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled 
 int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
 int g_opt_march_waves = 1280;       // target number of waves of the z-marching forward kernel
 int g_opt_pair_fwd = 1;             // 1: forward passes of two shots run concurrently on two streams
+int g_opt_pair_bwd = 0;             // 1: backward passes of two shots run concurrently (slower at 2000x1000: the pair does not fit the Infinity Cache)
+int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 never, 1 always, 2 only while two backward passes overlap
+int g_opt_early = 1;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
+int g_opt_pipe_bwd = 0;             // 1: backward of shot k overlaps the forward of shot k+1 (session.cpp)
 int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
 struct Cell {
@@ -76,7 +80,22 @@ __device__ __forceinline__ Cell my_cell(const Grid &g) {
 // ---------------------------------------------------------------------------------------------
 // stress update
 // ---------------------------------------------------------------------------------------------
-template <bool FWD, bool SAVE>
+// Accumulator update.  NT: non-temporal accesses keep the imaging accumulators out of the 256 MB Infinity Cache
+// (scripts/probes/bw_probe3.hip) so that the fields of two concurrently running backward passes stay resident.
+template <bool NT>
+__device__ __forceinline__ float acc_load(const float *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void acc_store(float *p, float v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+template <bool FWD, bool SAVE, bool NT = false>
 __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
@@ -100,7 +119,15 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
         }
         if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_stress.cu:52
 
+        // every unconditional load of the cell is issued here, before the first store: a store makes the compiler
+        // keep all later (may-alias) loads behind it, i.e. one more dependent memory round trip per wave
         const float vz0 = f.vz[i], vx0 = f.vx[i], vxm1 = f.vx[i - 1];
+        float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], vz0, f.vz[i + P], g.rdz);
+        float dvx_dx = dminus(f.vx[i - 2], vxm1, vx0, f.vx[i + 1], g.rdx);
+        float dvx_dz = dplus(f.vx[i - P], vx0, f.vx[i + P], f.vx[i + 2 * P], g.rdz);
+        float dvz_dx = dplus(f.vz[i - 1], vz0, f.vz[i + 1], f.vz[i + 2], g.rdx);
+        const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
+        const float szz0 = f.szz[i], sxx0 = f.sxx[i], sxz0 = f.sxz[i];
         if (lr.n && z == lr.z) {
             // line receivers: seismogram column `it` = velocities at the START of step `it`, which this kernel
             // only reads (recording_vx / _vz / _exx, utilities.cu:593-602,645-677)
@@ -111,10 +138,6 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
                 if (lr.d_ett) lr.d_ett[r] = vx0 - vxm1;
             }
         }
-        float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], vz0, f.vz[i + P], g.rdz);
-        float dvx_dx = dminus(f.vx[i - 2], vxm1, vx0, f.vx[i + 1], g.rdx);
-        float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
-        float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
 
         if (in_pml_z(g, z)) {  // wave-uniform branch
             float p = pc.b_z[z] * m.dvz_dz[i] + pc.a_z[z] * dvz_dz;
@@ -132,17 +155,16 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             m.dvz_dx[i] = q;
             dvz_dx = dvz_dx * pc.rK_xh[x] + q;
         }
-        const float lam = md.lam[i], mu = md.mu[i];
         const float l2m = lam + 2.0f * mu;
-        float szz = f.szz[i] + (l2m * dvz_dz + lam * dvx_dx) * g.dt;
-        float sxx = f.sxx[i] + (lam * dvz_dz + l2m * dvx_dx) * g.dt;
+        float szz = szz0 + (l2m * dvz_dz + lam * dvx_dx) * g.dt;
+        float sxx = sxx0 + (lam * dvz_dz + l2m * dvx_dx) * g.dt;
         if (z == z_src && x == x_src) {  // add_source, utilities.cu:531-538
             szz += src_amp;
             sxx += src_amp;
         }
         f.szz[i] = szz;
         f.sxx[i] = sxx;
-        f.sxz[i] += md.ave_mu[i] * (dvx_dz + dvz_dx) * g.dt;
+        f.sxz[i] = sxz0 + amu * (dvx_dz + dvz_dx) * g.dt;
     } else {
         // ---- reverse-time reconstruction + lambda/mu imaging ----
         const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
@@ -161,16 +183,17 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             const float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
             const float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
             const float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
-            const float lam = md.lam[i], mu = md.mu[i];
+            const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
+            const float za = adj.szz[i], xa = adj.sxx[i], sa = adj.sxz[i];
+            const float g_lam = acc_load<NT>(acc.lam + i), g_mu = acc_load<NT>(acc.mu + i), g_xz = acc_load<NT>(acc.xz + i);
             const float l2m = lam + 2.0f * mu;
             szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
             sxx -= (lam * dvz_dz + l2m * dvx_dx) * g.dt;
-            sxz -= md.ave_mu[i] * (dvx_dz + dvz_dx) * g.dt;
+            sxz -= amu * (dvx_dz + dvz_dx) * g.dt;
             // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
-            const float za = adj.szz[i], xa = adj.sxx[i], sa = adj.sxz[i];
-            acc.lam[i] += -(za + xa) * (dvz_dz + dvx_dx) * g.dt;
-            acc.mu[i] += -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt;
-            acc.xz[i] += -sa * (dvx_dz + dvz_dx) * g.dt;
+            acc_store<NT>(acc.lam + i, g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt);
+            acc_store<NT>(acc.mu + i, g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt);
+            acc_store<NT>(acc.xz + i, g_xz + -sa * (dvx_dz + dvz_dx) * g.dt);
         }
         if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
             const int L = g.frame_len;
@@ -187,7 +210,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
 // ---------------------------------------------------------------------------------------------
 // velocity update
 // ---------------------------------------------------------------------------------------------
-template <bool FWD>
+template <bool FWD, bool NT = false>
 __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
                                               float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
@@ -202,6 +225,7 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
         float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
         float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
         float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+        const float vz0 = f.vz[i], vx0 = f.vx[i], ba = md.byc_a[i], bb = md.byc_b[i];  // all loads before the first store
         if (in_pml_z(g, z)) {
             float p = pc.b_zh[z] * m.dszz_dz[i] + pc.a_zh[z] * dszz_dz;
             m.dszz_dz[i] = p;
@@ -218,8 +242,8 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             m.dsxx_dx[i] = q;
             dsxx_dx = dsxx_dx * pc.rK_xh[x] + q;
         }
-        f.vz[i] += (dszz_dz + dsxz_dx) * md.byc_a[i] * g.dt;
-        f.vx[i] += (dsxz_dz + dsxx_dx) * md.byc_b[i] * g.dt;
+        f.vz[i] = vz0 + (dszz_dz + dsxz_dx) * ba * g.dt;
+        f.vx[i] = vx0 + (dsxz_dz + dsxx_dx) * bb * g.dt;
     } else {
         // source_grad uses the adjoint stresses as they stand at the start of the step (libCUFD.cu:547)
         if (z == z_src && x == x_src) *stf_grad_it = -(adj.szz[i] + src_rxz * adj.sxx[i]) * g.dt;
@@ -232,11 +256,12 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             const float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
             const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
             const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+            const float g_a = acc_load<NT>(acc.a + i), g_b = acc_load<NT>(acc.b + i), avz = adj.vz[i], avx = adj.vx[i];
             vz = f.vz[i] - (dszz_dz + dsxz_dx) * md.byc_a[i] * g.dt;
             vx = f.vx[i] - (dsxz_dz + dsxx_dx) * md.byc_b[i] * g.dt;
             // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
-            acc.a[i] += -adj.vz[i] * (dszz_dz + dsxz_dx) * g.dt;
-            acc.b[i] += -adj.vx[i] * (dsxz_dz + dsxx_dx) * g.dt;
+            acc_store<NT>(acc.a + i, g_a + -avz * (dszz_dz + dsxz_dx) * g.dt);
+            acc_store<NT>(acc.b + i, g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt);
         }
         if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
             const int L = g.frame_len;
@@ -252,26 +277,65 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
 // adjoint velocity update.  el_velocity_adj.cu:57-102.  `f` holds the ADJOINT fields.
 // The a*dpsi terms are evaluated only where a != 0 (inside the PML strips; a is exactly 0 elsewhere,
 // utilities.cu:272-275,347-353), which lets k_stress_adj keep psi only near the strips.
+// Split into LOAD (every unconditional global load of the cell, issued back to back) and APPLY (arithmetic, the
+// rare C-PML branches, stores): a wave waits once for all of them, and the fused backward kernels can issue the
+// LOAD of their second update before the first update's stores (a store keeps later may-alias loads behind it).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
-                                                  const Media &md, const PmlCoef &pc, const LineRec &lr) {
+struct VelAdjIn {
+    bool on;
+    float szz_xm1, szz_0, szz_xp1, szz_xp2, szz_zm1, szz_zp1, szz_zp2;
+    float sxx_xm1, sxx_0, sxx_xp1, sxx_xp2, sxx_zm1, sxx_zp1, sxx_zp2;
+    float sxz_zm2, sxz_zm1, sxz_0, sxz_zp1, sxz_xm2, sxz_xm1, sxz_xp1;
+    float vx, vz, lam, mu, amu, rKx, rKxh, rKz, rKzh;
+};
+__device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell &c, const Fields &f, const Media &md,
+                                                      const PmlCoef &pc) {
+    VelAdjIn q;
     const int z = c.z, x = c.x, P = g.pitch;
-    if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
+    q.on = !(z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3);
+    if (!q.on) return q;
+    const size_t i = c.i;
+    q.szz_xm1 = f.szz[i - 1]; q.szz_0 = f.szz[i]; q.szz_xp1 = f.szz[i + 1]; q.szz_xp2 = f.szz[i + 2];
+    q.szz_zm1 = f.szz[i - P]; q.szz_zp1 = f.szz[i + P]; q.szz_zp2 = f.szz[i + 2 * P];
+    q.sxx_xm1 = f.sxx[i - 1]; q.sxx_0 = f.sxx[i]; q.sxx_xp1 = f.sxx[i + 1]; q.sxx_xp2 = f.sxx[i + 2];
+    q.sxx_zm1 = f.sxx[i - P]; q.sxx_zp1 = f.sxx[i + P]; q.sxx_zp2 = f.sxx[i + 2 * P];
+    q.sxz_zm2 = f.sxz[i - 2 * P]; q.sxz_zm1 = f.sxz[i - P]; q.sxz_0 = f.sxz[i]; q.sxz_zp1 = f.sxz[i + P];
+    q.sxz_xm2 = f.sxz[i - 2]; q.sxz_xm1 = f.sxz[i - 1]; q.sxz_xp1 = f.sxz[i + 1];
+    q.vx = f.vx[i]; q.vz = f.vz[i];
+    q.lam = md.lam[i]; q.mu = md.mu[i]; q.amu = md.ave_mu[i];
+    q.rKx = pc.rK_x[x]; q.rKxh = pc.rK_xh[x]; q.rKz = pc.rK_z[z]; q.rKzh = pc.rK_zh[z];
+    return q;
+}
+__device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
+                                                   const PmlMem &m, const Media &md, const PmlCoef &pc, const LineRec &lr) {
+    if (!q.on) return;
+    const int z = c.z, x = c.x, P = g.pitch;
     const size_t i = c.i;
     const bool pz = in_pml_z(g, z);
     const bool px = (x < g.nPml || x > g.nx - g.nPml - 1);
-    const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
-    const float l2m = lam + 2.0f * mu;
-    const float rKx = pc.rK_x[x], rKxh = pc.rK_xh[x], rKz = pc.rK_z[z], rKzh = pc.rK_zh[z];
+    const float lam = q.lam, amu = q.amu;
+    const float l2m = lam + 2.0f * q.mu;
 
     // vx
-    const float dszz_dx = -dplus(f.szz[i - 1], f.szz[i], f.szz[i + 1], f.szz[i + 2], g.rdx);
-    const float dsxx_dx = -dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
-    const float dsxz_dz = -dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
-    float upd = lam * dszz_dx * rKx * g.dt + l2m * dsxx_dx * rKx * g.dt + amu * rKzh * dsxz_dz * g.dt;
-    if (px) upd += pc.a_x[x] * -dplus(m.dvx_dx[i - 1], m.dvx_dx[i], m.dvx_dx[i + 1], m.dvx_dx[i + 2], g.rdx);
-    if (pz) upd += pc.a_zh[z] * -dminus(m.dvx_dz[i - 2 * P], m.dvx_dz[i - P], m.dvx_dz[i], m.dvx_dz[i + P], g.rdz);
-    const float vx = f.vx[i] + upd;
+    const float dszz_dx = -dplus(q.szz_xm1, q.szz_0, q.szz_xp1, q.szz_xp2, g.rdx);
+    const float dsxx_dx = -dplus(q.sxx_xm1, q.sxx_0, q.sxx_xp1, q.sxx_xp2, g.rdx);
+    const float dsxz_dz = -dminus(q.sxz_zm2, q.sxz_zm1, q.sxz_0, q.sxz_zp1, g.rdz);
+    float upd = lam * dszz_dx * q.rKx * g.dt + l2m * dsxx_dx * q.rKx * g.dt + amu * q.rKzh * dsxz_dz * g.dt;
+    // vz
+    const float dszz_dz = -dplus(q.szz_zm1, q.szz_0, q.szz_zp1, q.szz_zp2, g.rdz);
+    const float dsxx_dz = -dplus(q.sxx_zm1, q.sxx_0, q.sxx_zp1, q.sxx_zp2, g.rdz);
+    const float dsxz_dx = -dminus(q.sxz_xm2, q.sxz_xm1, q.sxz_0, q.sxz_xp1, g.rdx);
+    float upz = l2m * dszz_dz * q.rKz * g.dt + lam * dsxx_dz * q.rKz * g.dt + amu * q.rKxh * dsxz_dx * g.dt;
+    if (px) {
+        upd += pc.a_x[x] * -dplus(m.dvx_dx[i - 1], m.dvx_dx[i], m.dvx_dx[i + 1], m.dvx_dx[i + 2], g.rdx);
+        upz += pc.a_xh[x] * -dminus(m.dvz_dx[i - 2], m.dvz_dx[i - 1], m.dvz_dx[i], m.dvz_dx[i + 1], g.rdx);
+    }
+    if (pz) {
+        upd += pc.a_zh[z] * -dminus(m.dvx_dz[i - 2 * P], m.dvx_dz[i - P], m.dvx_dz[i], m.dvx_dz[i + P], g.rdz);
+        upz += pc.a_z[z] * -dplus(m.dvz_dz[i - P], m.dvz_dz[i], m.dvz_dz[i + P], m.dvz_dz[i + 2 * P], g.rdz);
+    }
+    const float vx = q.vx + upd;
+    const float vz = q.vz + upz;
     {
         // res_injection_exx (utilities.cu:605-615) for line receivers, applied by the thread that owns the cell:
         // vx_adj(z,x) += r[x]; vx_adj(z,x) -= r[x+1]   (after this kernel's update, libCUFD.cu:585-610)
@@ -283,76 +347,105 @@ __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, 
         }
         f.vx[i] = vs;
     }
-    if (px || pz) {  // the buoyancies are only needed inside the layers: keep their loads out of the interior
-        const float bb = md.byc_b[i];
-        if (px) m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
-        if (pz) m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
-    }
-
-    // vz
-    const float dszz_dz = -dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
-    const float dsxx_dz = -dplus(f.sxx[i - P], f.sxx[i], f.sxx[i + P], f.sxx[i + 2 * P], g.rdz);
-    const float dsxz_dx = -dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
-    float upz = l2m * dszz_dz * rKz * g.dt + lam * dsxx_dz * rKz * g.dt + amu * rKxh * dsxz_dx * g.dt;
-    if (pz) upz += pc.a_z[z] * -dplus(m.dvz_dz[i - P], m.dvz_dz[i], m.dvz_dz[i + P], m.dvz_dz[i + 2 * P], g.rdz);
-    if (px) upz += pc.a_xh[x] * -dminus(m.dvz_dx[i - 2], m.dvz_dx[i - 1], m.dvz_dx[i], m.dvz_dx[i + 1], g.rdx);
-    const float vz = f.vz[i] + upz;
     f.vz[i] = vz;
-    if (px || pz) {
-        const float ba = md.byc_a[i];
-        if (px) m.dsxz_dx[i] = pc.b_x[x] * m.dsxz_dx[i] + ba * vz * g.dt;
-        if (pz) m.dszz_dz[i] = pc.b_zh[z] * m.dszz_dz[i] + ba * vz * g.dt;
+    if (px || pz) {  // the buoyancies are only needed inside the layers: keep their loads out of the interior
+        const float bb = md.byc_b[i], ba = md.byc_a[i];
+        if (px) {
+            m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
+            m.dsxz_dx[i] = pc.b_x[x] * m.dsxz_dx[i] + ba * vz * g.dt;
+        }
+        if (pz) {
+            m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
+            m.dszz_dz[i] = pc.b_zh[z] * m.dszz_dz[i] + ba * vz * g.dt;
+        }
     }
+}
+__device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
+                                                  const Media &md, const PmlCoef &pc, const LineRec &lr) {
+    const VelAdjIn q = velocity_adj_load(g, c, f, md, pc);
+    velocity_adj_apply(q, g, c, f, m, md, pc, lr);
 }
 
 // ---------------------------------------------------------------------------------------------
 // adjoint stress update.  el_stress_adj.cu:53-97.  The reference updates the four psi arrays over
 // the whole domain (strip tests commented out, :67-72,:88-95); they are only ever READ through
 // stencils multiplied by a (zero outside the strips), so updating them on the strips widened by
-// the stencil radius (2) gives identical results.
+// the stencil radius (2) gives identical results.  LOAD / APPLY split as above.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
-                                                const Media &md, const PmlCoef &pc) {
+struct StressAdjIn {
+    bool on;
+    float vz_xm1, vz_0, vz_xp1, vz_xp2, vz_zm2, vz_zm1, vz_zp1;
+    float vx_zm1, vx_0, vx_zp1, vx_zp2, vx_xm2, vx_xm1, vx_xp1;
+    float sxz, sxx, szz, ba, bb, rKx, rKxh, rKz, rKzh;
+};
+__device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell &c, const Fields &f, const Media &md,
+                                                       const PmlCoef &pc) {
+    StressAdjIn q;
     const int z = c.z, x = c.x, P = g.pitch;
-    if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;
+    q.on = !(z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3);
+    if (!q.on) return q;
+    const size_t i = c.i;
+    q.vz_xm1 = f.vz[i - 1]; q.vz_0 = f.vz[i]; q.vz_xp1 = f.vz[i + 1]; q.vz_xp2 = f.vz[i + 2];
+    q.vz_zm2 = f.vz[i - 2 * P]; q.vz_zm1 = f.vz[i - P]; q.vz_zp1 = f.vz[i + P];
+    q.vx_zm1 = f.vx[i - P]; q.vx_0 = f.vx[i]; q.vx_zp1 = f.vx[i + P]; q.vx_zp2 = f.vx[i + 2 * P];
+    q.vx_xm2 = f.vx[i - 2]; q.vx_xm1 = f.vx[i - 1]; q.vx_xp1 = f.vx[i + 1];
+    q.sxz = f.sxz[i]; q.sxx = f.sxx[i]; q.szz = f.szz[i];
+    q.ba = md.byc_a[i]; q.bb = md.byc_b[i];
+    q.rKx = pc.rK_x[x]; q.rKxh = pc.rK_xh[x]; q.rKz = pc.rK_z[z]; q.rKzh = pc.rK_zh[z];
+    return q;
+}
+__device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
+                                                 const PmlMem &m, const Media &md, const PmlCoef &pc) {
+    if (!q.on) return;
+    const int z = c.z, x = c.x, P = g.pitch;
     const size_t i = c.i;
     const bool pz = in_pml_z(g, z);
     const bool px = (x < g.nPml || x > g.nx - g.nPml - 1);
     const bool wz = (z < g.nPml + 2 || z > g.nzc - g.nPml - 3);  // psi needed by stencils centred in the strip
     const bool wx = (x < g.nPml + 2 || x > g.nx - g.nPml - 3);
-    const float ba = md.byc_a[i], bb = md.byc_b[i];
+    const float ba = q.ba, bb = q.bb;
 
     // sxz
-    const float dvz_dx = -dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
-    const float dvx_dz = -dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
-    float us = dvz_dx * pc.rK_x[x] * ba * g.dt + dvx_dz * pc.rK_z[z] * bb * g.dt;
-    if (px) us += pc.a_x[x] * -dplus(m.dsxz_dx[i - 1], m.dsxz_dx[i], m.dsxz_dx[i + 1], m.dsxz_dx[i + 2], g.rdx);
-    if (pz) us += pc.a_z[z] * -dplus(m.dsxz_dz[i - P], m.dsxz_dz[i], m.dsxz_dz[i + P], m.dsxz_dz[i + 2 * P], g.rdz);
-    const float sxz = f.sxz[i] + us;
-    f.sxz[i] = sxz;
-    if (wx || wz) {  // lambda, mu, ave_mu only feed the memory variables, which only exist near the layers
-        const float amu = md.ave_mu[i];
-        if (wx) m.dvz_dx[i] = pc.b_xh[x] * m.dvz_dx[i] + sxz * amu * g.dt;
-        if (wz) m.dvx_dz[i] = pc.b_zh[z] * m.dvx_dz[i] + sxz * amu * g.dt;
-    }
-
+    const float dvz_dx = -dplus(q.vz_xm1, q.vz_0, q.vz_xp1, q.vz_xp2, g.rdx);
+    const float dvx_dz = -dplus(q.vx_zm1, q.vx_0, q.vx_zp1, q.vx_zp2, g.rdz);
+    float us = dvz_dx * q.rKx * ba * g.dt + dvx_dz * q.rKz * bb * g.dt;
     // sxx, szz
-    const float dvx_dx = -dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
-    const float dvz_dz = -dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
-    float ux = bb * dvx_dx * pc.rK_xh[x] * g.dt;
-    float uz = ba * dvz_dz * pc.rK_zh[z] * g.dt;
-    if (px) ux += pc.a_xh[x] * -dminus(m.dsxx_dx[i - 2], m.dsxx_dx[i - 1], m.dsxx_dx[i], m.dsxx_dx[i + 1], g.rdx);
-    if (pz) uz += pc.a_zh[z] * -dminus(m.dszz_dz[i - 2 * P], m.dszz_dz[i - P], m.dszz_dz[i], m.dszz_dz[i + P], g.rdz);
-    const float sxx = f.sxx[i] + ux;
-    const float szz = f.szz[i] + uz;
+    const float dvx_dx = -dminus(q.vx_xm2, q.vx_xm1, q.vx_0, q.vx_xp1, g.rdx);
+    const float dvz_dz = -dminus(q.vz_zm2, q.vz_zm1, q.vz_0, q.vz_zp1, g.rdz);
+    float ux = bb * dvx_dx * q.rKxh * g.dt;
+    float uz = ba * dvz_dz * q.rKzh * g.dt;
+    if (px) {
+        us += pc.a_x[x] * -dplus(m.dsxz_dx[i - 1], m.dsxz_dx[i], m.dsxz_dx[i + 1], m.dsxz_dx[i + 2], g.rdx);
+        ux += pc.a_xh[x] * -dminus(m.dsxx_dx[i - 2], m.dsxx_dx[i - 1], m.dsxx_dx[i], m.dsxx_dx[i + 1], g.rdx);
+    }
+    if (pz) {
+        us += pc.a_z[z] * -dplus(m.dsxz_dz[i - P], m.dsxz_dz[i], m.dsxz_dz[i + P], m.dsxz_dz[i + 2 * P], g.rdz);
+        uz += pc.a_zh[z] * -dminus(m.dszz_dz[i - 2 * P], m.dszz_dz[i - P], m.dszz_dz[i], m.dszz_dz[i + P], g.rdz);
+    }
+    const float sxz = q.sxz + us;
+    const float sxx = q.sxx + ux;
+    const float szz = q.szz + uz;
+    f.sxz[i] = sxz;
     f.sxx[i] = sxx;
     f.szz[i] = szz;
-    if (wx || wz) {
+    if (wx || wz) {  // lambda, mu, ave_mu only feed the memory variables, which only exist near the layers
+        const float amu = md.ave_mu[i];
         const float lam = md.lam[i], mu = md.mu[i];
         const float l2m = lam + 2.0f * mu;
-        if (wx) m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
-        if (wz) m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+        if (wx) {
+            m.dvz_dx[i] = pc.b_xh[x] * m.dvz_dx[i] + sxz * amu * g.dt;
+            m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
+        }
+        if (wz) {
+            m.dvx_dz[i] = pc.b_zh[z] * m.dvx_dz[i] + sxz * amu * g.dt;
+            m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+        }
     }
+}
+__device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
+                                                const Media &md, const PmlCoef &pc) {
+    const StressAdjIn q = stress_adj_load(g, c, f, md, pc);
+    stress_adj_apply(q, g, c, f, m, md, pc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,6 +529,7 @@ __device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int
                    cx, cx + nx,  cx + 2 * nx,  cx + 3 * nx,  cx + 4 * nx,  cx + 5 * nx};
 }
 
+template <bool NT, bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *__restrict__ frame_t) {
     const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
     const PmlMem m = mem_of(b.mem, b.n);
@@ -443,9 +537,16 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
     const ImgAcc acc = acc_of(b.acc, b.n);
     const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
-    velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
-    stress_adj_body(g, c, adj, m, md, pc);
+    if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
+        const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
+        velocity_body<false, NT>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        stress_adj_apply(q, g, c, adj, m, md, pc);
+    } else {
+        velocity_body<false, NT>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        stress_adj_body(g, c, adj, m, md, pc);
+    }
 }
+template <bool NT, bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__restrict__ frame_t, int zx_src /* z<<16 | x */,
                                                 float src_amp, float src_rxz, float *__restrict__ stf_grad_it,
                                                 int lr_zx /* z<<16 | x0 */, int lr_n, const float *__restrict__ lr_res) {
@@ -459,8 +560,14 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
     const Cell c = my_cell(g);
     // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
     if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
-    stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
-    velocity_adj_body(g, c, adj, m, md, pc, lr);
+    if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
+        const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
+        stress_body<false, false, NT>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
+    } else {
+        stress_body<false, false, NT>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        velocity_adj_body(g, c, adj, m, md, pc, lr);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,6 +771,10 @@ int get_kernel_option(const char *name) {
     if (n == "probe") return g_opt_probe;
     if (n == "march_waves") return g_opt_march_waves;
     if (n == "pair_fwd") return g_opt_pair_fwd;
+    if (n == "pipe_bwd") return g_opt_pipe_bwd;
+    if (n == "pair_bwd") return g_opt_pair_bwd;
+    if (n == "early") return g_opt_early;
+    if (n == "acc_nt") return g_opt_acc_nt;
     return -1;
 }
 
@@ -677,6 +788,10 @@ int set_kernel_option(const char *name, int value) {
     if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
     if (n == "march_waves" && value >= 1) { g_opt_march_waves = value; return 0; }
     if (n == "pair_fwd") { g_opt_pair_fwd = value ? 1 : 0; return 0; }
+    if (n == "pipe_bwd") { g_opt_pipe_bwd = value ? 1 : 0; return 0; }
+    if (n == "pair_bwd") { g_opt_pair_bwd = value ? 1 : 0; return 0; }
+    if (n == "early" && value >= 0 && value <= 3) { g_opt_early = value; return 0; }
+    if (n == "acc_nt" && value >= 0 && value <= 2) { g_opt_acc_nt = value; return 0; }
     return -1;
 }
 
@@ -745,23 +860,34 @@ void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media
 }
 
 void launch_bwd_a(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
-                  ImgAcc acc) {
+                  ImgAcc acc, bool acc_nt) {
     const Grid g = tiled(g0);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    hipLaunchKernelGGL(k_bwd_a, field_grid(g), BLOCK, 0, st, g, b, frame_t);
+    const bool early = (g_opt_early & 1) != 0;
+    auto k = acc_nt ? (early ? k_bwd_a<true, true> : k_bwd_a<true, false>) : (early ? k_bwd_a<false, true> : k_bwd_a<false, false>);
+    hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
 
 void launch_bwd_b(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
                   int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
-                  hipEvent_t ev_start, hipEvent_t ev_stop) {
+                  hipEvent_t ev_start, hipEvent_t ev_stop, bool acc_nt) {
     const Grid g = tiled(g0);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
+    const bool early = (g_opt_early & 2) != 0;
+    auto k = acc_nt ? (early ? k_bwd_b<true, true> : k_bwd_b<true, false>) : (early ? k_bwd_b<false, true> : k_bwd_b<false, false>);
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
-        hipExtLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
+        hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
                               src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
     else
-        hipLaunchKernelGGL(k_bwd_b, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
+        hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
+}
+
+__global__ void k_add_inplace(float *__restrict__ a, const float *__restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n) {
+    hipLaunchKernelGGL(k_add_inplace, dim3(4096), dim3(256), 0, st, a, b, n);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

@@ -21,10 +21,11 @@ void launch_bwd_stress(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media 
                        int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start = nullptr,
                        hipEvent_t ev_stop = nullptr);
 void launch_bwd_a(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
-                  ImgAcc acc);
+                  ImgAcc acc, bool acc_nt = false);
 void launch_bwd_b(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
                   int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
-                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool acc_nt = false);
+void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
 int get_kernel_option_bwd_fuse();
 int get_kernel_option(const char *name);
 // fused forward step (fwd_fused.hip)

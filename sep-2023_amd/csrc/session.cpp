@@ -112,7 +112,6 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     grad_stage_ = dalloc<float>(3 * dense);
     scal_ = dalloc<double>(4);
     cp2_bits_ = dalloc<unsigned int>(4);
-    stf_grad_ = dalloc<float>((size_t)par.nSteps);
 
     // ---- C-PML profiles (host) -> device, with 1/K precomputed ----
     {
@@ -194,6 +193,12 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
 Session::~Session() {
     (void)hipSetDevice(gpu_id_);
     (void)hipDeviceSynchronize();
+    if (bwd_mem_.dvz_dz) (void)hipFree(bwd_mem_.dvz_dz);
+    if (bwd2_mem_.dvz_dz) (void)hipFree(bwd2_mem_.dvz_dz);
+    for (int k = 0; k < 2; k++) {
+        if (ev_fwd_[k]) (void)hipEventDestroy(ev_fwd_[k]);
+        if (ev_bwd_[k]) (void)hipEventDestroy(ev_bwd_[k]);
+    }
     if (lane2_state_) (void)hipFree(lane2_state_);
     if (frame2_) (void)hipFree(frame2_);
     if (syn2_) (void)hipFree(syn2_);
@@ -203,6 +208,7 @@ Session::~Session() {
     for (auto &kv : obs_) (void)hipFree(kv.second.d_ett);
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
+    if (stf_grad_) (void)hipFree(stf_grad_);
     if (h_io_) (void)hipHostFree(h_io_);
     for (auto &e : ev_) (void)hipEventDestroy(e);
     for (auto &e : probe_ev_) (void)hipEventDestroy(e);
@@ -226,6 +232,35 @@ void Session::ensure_lane2(bool with_frames) {
         const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
         HIP_OK(hipMalloc((void **)&frame2_, fb));
         device_bytes_ += (long long)fb;
+    }
+}
+
+// Second backward lane: memory variables, adjoint fields and imaging accumulators (zero between calls).
+void Session::ensure_bwd_lane2(hipStream_t st) {
+    const size_t n = cells_;
+    if (bwd2_mem_.dvz_dz) return;
+    float *b = nullptr;
+    HIP_OK(hipMalloc((void **)&b, 18 * n * sizeof(float)));
+    device_bytes_ += (long long)(18 * n * sizeof(float));
+    bwd2_mem_ = PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
+    b += 8 * n;
+    bwd2_adj_ = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
+    b += 5 * n;
+    bwd2_acc_ = ImgAcc{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
+    (void)st;
+}
+
+// Memory variables of the backward pass when it overlaps a forward pass (pipe_bwd), plus the pipeline's events.
+void Session::ensure_bwd_mem() {
+    const size_t n = cells_;
+    if (bwd_mem_.dvz_dz) return;
+    float *b = nullptr;
+    HIP_OK(hipMalloc((void **)&b, 8 * n * sizeof(float)));
+    device_bytes_ += (long long)(8 * n * sizeof(float));
+    bwd_mem_ = PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
+    for (int k = 0; k < 2; k++) {
+        HIP_OK(hipEventCreateWithFlags(&ev_fwd_[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ev_bwd_[k], hipEventDisableTiming));
     }
 }
 
@@ -344,7 +379,6 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     probe_calls_ = 0;
     fwd_steps_ = bwd_steps_ = 0;
     std::vector<float> h_gstf;
-    if (withAdj) h_gstf.resize(nSteps);
 
     // Per-shot context.  Two "lanes" of forward state exist so that the forward passes of two shots can run
     // concurrently on two streams (their kernel-boundary gaps and tails fill each other: x1.2 on the forward
@@ -364,8 +398,27 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         hipStream_t st;
     };
     const int fuse_fwd = get_kernel_option("fwd_fuse");
+    if (withAdj) {  // source-time-function gradients of all shots of the call, one row each
+        const size_t need = (size_t)group_size * nSteps;
+        if (need > stf_grad_len_) {
+            if (stf_grad_) (void)hipFree(stf_grad_);
+            stf_grad_ = nullptr;
+            HIP_OK(hipMalloc((void **)&stf_grad_, need * sizeof(float)));
+            device_bytes_ += (long long)((need - stf_grad_len_) * sizeof(float));
+            stf_grad_len_ = need;
+        }
+        HIP_OK(hipMemsetAsync(stf_grad_, 0, need * sizeof(float), st));
+    }
+    if (if_res)  // observed data of every shot of the call resident before the time loops start
+        for (int is = 0; is < group_size; is++) (void)observed_ett(shot_ids[is], survey_.shots[shot_ids[is]].nrec, st);
     const bool can_pair = (fuse_fwd == 0) && get_kernel_option("pair_fwd") != 0 && group_size >= 2;
+    const bool pair_bwd = can_pair && withAdj && get_kernel_option("pair_bwd") != 0;
     if (can_pair) ensure_lane2(withAdj);
+    if (pair_bwd) {
+        ensure_bwd_lane2(st);
+        HIP_OK(hipMemsetAsync(bwd2_acc_.lam, 0, 5 * n * sizeof(float), st));
+    }
+    lane2_acc_used_ = false;
 
     auto make_ctx = [&](int is, int lane, hipStream_t lane_st) -> ShotCtx {
         ShotCtx c{};
@@ -550,71 +603,160 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         dump("Residual_Shot", obs_pr.data());
     };
-    // backward of one shot on the main stream (libCUFD.cu:500-675)
-    auto backward = [&](const ShotCtx &c) {
+    // ---------------- backward of one shot (libCUFD.cu:500-675) ----------------
+    // A backward lane = stream + backward-pass memory variables + adjoint fields + imaging accumulators.
+    struct BwdLane {
+        hipStream_t s;
+        PmlMem bm;
+        Fields adj;
+        ImgAcc acc;
+        bool nt, probe;
+    };
+    const int fuse_bwd = get_kernel_option_bwd_fuse();
+    const int probe = get_kernel_option("probe");
+    int n_probe = 0;
+    auto backward_init = [&](const BwdLane &L) {
         // adjoint fields + all eight memory variables restart from zero (:503-515); the two pre-loop
         // adjoint launches (:520-542) act on all-zero arrays and change nothing.
-        HIP_OK(hipMemsetAsync(state_ + 5 * n, 0, 13 * n * sizeof(float), st));
-        HIP_OK(hipMemsetAsync(stf_grad_, 0, (size_t)nSteps * sizeof(float), st));
-        HIP_OK(hipEventRecord(ev_[2], st));
-        const int fuse = get_kernel_option_bwd_fuse();
-        const int probe = get_kernel_option("probe");
-        int n_probe = 0;
+        HIP_OK(hipMemsetAsync(L.bm.dvz_dz, 0, 8 * n * sizeof(float), L.s));
+        HIP_OK(hipMemsetAsync(L.adj.vz, 0, 5 * n * sizeof(float), L.s));
+    };
+    auto backward_step = [&](const ShotCtx &c, const BwdLane &L, int it) {
         const bool inj_inl = c.line.n > 0 && get_kernel_option("line_fuse") != 0;
         const Shot &sh = *c.sh;
-        for (int it = nSteps - 2; it >= 0; it--) {
-            float *frame_t = c.frame + (size_t)it * 5 * (size_t)g.frame_len;
-            const float amp = src_scale * c.stf_s[it] * par_.dt;
-            const float *res_t = c.res + (size_t)it * c.nrec;
-            LineRec lr{};
-            if (inj_inl) {
-                lr = c.line;
-                lr.res = res_t;
-            }
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0 && fuse != 0) {
-                e0 = probe_ev_[2 * n_probe];
-                e1 = probe_ev_[2 * n_probe + 1];
-                n_probe++;
-            }
-            if (fuse == 2) {
-                launch_bwd_a(st, g, c.fcur, mem_, md_, pc_, frame_t, adj_, acc_);
-                launch_bwd_b(st, g, c.fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_, lr, e0, e1);
-                if (!inj_inl) launch_inject(st, adj_, c.nrec, c.rec, res_t);
-                launches_ += inj_inl ? 2 : 3;
-            } else if (fuse == 1) {
-                launch_bwd_velocity(st, g, c.fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_, lr);
-                if (!inj_inl) launch_inject(st, adj_, c.nrec, c.rec, res_t);
-                launch_bwd_stress(st, g, c.fcur, mem_, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_, e0, e1);
-                launches_ += 3;
-            } else {
-                launch_velocity_rev(st, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, stf_grad_ + it, adj_, acc_);
-                launch_stress_rev(st, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, adj_, acc_);
-                launch_velocity_adj(st, g, adj_, mem_, md_, pc_);
-                launch_inject(st, adj_, c.nrec, c.rec, res_t);
-                launch_stress_adj(st, g, adj_, mem_, md_, pc_);
-                launches_ += 5;
-            }
+        float *frame_t = c.frame + (size_t)it * 5 * (size_t)g.frame_len;
+        float *sg = stf_grad_ + (size_t)c.is * nSteps + it;
+        const float amp = src_scale * c.stf_s[it] * par_.dt;
+        const float *res_t = c.res + (size_t)it * c.nrec;
+        LineRec lr{};
+        if (inj_inl) {
+            lr = c.line;
+            lr.res = res_t;
         }
-        HIP_OK(hipEventRecord(ev_[3], st));
-        bwd_steps_ += nSteps - 1;
-        HIP_OK(hipStreamSynchronize(st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (L.probe && probe > 0 && n_probe < kProbePairs && (it % probe) == 0 && fuse_bwd != 0) {
+            e0 = probe_ev_[2 * n_probe];
+            e1 = probe_ev_[2 * n_probe + 1];
+            n_probe++;
+        }
+        if (fuse_bwd == 2) {
+            launch_bwd_a(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, L.adj, L.acc, L.nt);
+            launch_bwd_b(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1, L.nt);
+            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t);
+            launches_ += inj_inl ? 2 : 3;
+        } else if (fuse_bwd == 1) {
+            launch_bwd_velocity(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc, lr);
+            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t);
+            launch_bwd_stress(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc, e0, e1);
+            launches_ += 3;
+        } else {
+            launch_velocity_rev(L.s, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
+            launch_stress_rev(L.s, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
+            launch_velocity_adj(L.s, g, L.adj, L.bm, md_, pc_);
+            launch_inject(L.s, L.adj, c.nrec, c.rec, res_t);
+            launch_stress_adj(L.s, g, L.adj, L.bm, md_, pc_);
+            launches_ += 5;
+        }
+    };
+    auto collect_probes = [&]() {  // after a synchronisation of the main stream
         for (int k = 0; k < n_probe; k++) {
             float ms = 0.f;
             HIP_OK(hipEventElapsedTime(&ms, probe_ev_[2 * k], probe_ev_[2 * k + 1]));
             probe_us_ += 1e3 * ms;
             probe_calls_++;
         }
+        n_probe = 0;
+    };
+    const int acc_nt_opt = get_kernel_option("acc_nt");
+    // one shot (np == 1) or two shots concurrently, the second on stream 2 with its own adjoint state and accumulators
+    // (added to the first set before the gradients are finalised).  While two passes overlap, the accumulators are
+    // accessed non-temporally: 2 x (5 fields + 5 adjoint fields) + 5 media arrays = 220 MB stay in the Infinity Cache.
+    auto backward = [&](const ShotCtx *c, int np) {
+        BwdLane L[2];
+        L[0] = BwdLane{st, mem_, adj_, acc_, acc_nt_opt == 1 || (acc_nt_opt == 2 && np == 2), true};
+        if (np == 2) {
+            L[1] = BwdLane{stream2_, bwd2_mem_, bwd2_adj_, bwd2_acc_, L[0].nt, false};
+            lane2_acc_used_ = true;
+        }
+        HIP_OK(hipEventRecord(ev_[2], st));
+        if (np == 2) HIP_OK(hipStreamWaitEvent(stream2_, ev_[2], 0));
+        for (int k = 0; k < np; k++) backward_init(L[k]);
+        for (int it = nSteps - 2; it >= 0; it--)
+            for (int k = 0; k < np; k++) backward_step(c[k], L[k], it);
+        if (np == 2) {
+            HIP_OK(hipEventRecord(ev_join_, stream2_));
+            HIP_OK(hipStreamWaitEvent(st, ev_join_, 0));
+        }
+        HIP_OK(hipEventRecord(ev_[3], st));
+        bwd_steps_ += (long long)np * (nSteps - 1);
+        HIP_OK(hipStreamSynchronize(st));
+        collect_probes();
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
         bwd_ms_ += ms;
-        if (grad_stf) {
-            HIP_OK(hipMemcpy(h_gstf.data(), stf_grad_, (size_t)nSteps * sizeof(float), hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(grad_stf + (size_t)c.is * nSteps, h_gstf.data(), (size_t)nSteps * sizeof(float), hipMemcpyDefault));
-        }
     };
+    auto forward_inline = [&](const ShotCtx &c) { return c.line.n > 0 && !(c.comps & 1) && get_kernel_option("line_fuse") != 0; };
 
-    for (int is = 0; is < group_size;) {
+    const bool scratch_any = withAdj && !par_.scratch_dir_name.empty();
+    const bool pipelined = withAdj && fuse_fwd == 0 && get_kernel_option("pipe_bwd") != 0 && group_size >= 2 && !scratch_any;
+    if (pipelined) {
+        // Software pipeline over the shots of the call: while the backward pass of shot k runs on the main stream,
+        // the forward pass of shot k+1 runs on the second stream in the other lane (fields, memory variables,
+        // boundary frames, seismograms, residual are per lane; the backward pass has its own memory variables).
+        // Working set = 5 (forward lane) + 15 (backward) + 5 (media) arrays of 8.8 MB: still inside the 256 MB
+        // Infinity Cache, and each pass fills the kernel-boundary gaps and tails of the other.
+        ensure_lane2(true);
+        ensure_bwd_mem();
+        HIP_OK(hipEventRecord(ev_[0], st));
+        HIP_OK(hipStreamWaitEvent(stream2_, ev_[0], 0));
+        ShotCtx cur = make_ctx(0, 0, stream2_);
+        {
+            const bool inl = forward_inline(cur);
+            forward_init(cur);
+            for (int it = 0; it <= nSteps - 2; it++) forward_step(cur, it, inl);
+            if (inl) forward_last_column(cur);
+            residual(cur);
+            HIP_OK(hipEventRecord(ev_fwd_[0], stream2_));
+        }
+        for (int k = 0; k < group_size; k++) {
+            const bool has_next = k + 1 < group_size;
+            ShotCtx nxt{};
+            bool inl = false;
+            if (has_next) {
+                nxt = make_ctx(k + 1, (k + 1) & 1, stream2_);
+                inl = forward_inline(nxt);
+                if (k >= 1) HIP_OK(hipStreamWaitEvent(stream2_, ev_bwd_[(k + 1) & 1], 0));  // that lane's previous shot is fully consumed
+                forward_init(nxt);
+            }
+            HIP_OK(hipStreamWaitEvent(st, ev_fwd_[k & 1], 0));
+            const BwdLane BL{st, bwd_mem_, adj_, acc_, acc_nt_opt == 1, true};
+            backward_init(BL);
+            for (int j = 0; j <= nSteps - 2; j++) {
+                backward_step(cur, BL, nSteps - 2 - j);
+                if (has_next) forward_step(nxt, j, inl);
+            }
+            HIP_OK(hipEventRecord(ev_bwd_[k & 1], st));
+            if (has_next) {
+                if (inl) forward_last_column(nxt);
+                residual(nxt);
+                HIP_OK(hipEventRecord(ev_fwd_[(k + 1) & 1], stream2_));
+            }
+            cur = nxt;
+        }
+        HIP_OK(hipEventRecord(ev_[1], st));
+        fwd_steps_ += (long long)group_size * (nSteps - 1);
+        bwd_steps_ += (long long)group_size * (nSteps - 1);
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipStreamSynchronize(stream2_));
+        collect_probes();
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+        // forward and backward overlap: apportion the wall time by algorithmic bytes (60 : 124) for the statistics
+        fwd_ms_ += ms * (60.0 / 184.0);
+        bwd_ms_ += ms * (124.0 / 184.0);
+    }
+
+    for (int is = 0; is < group_size && !pipelined;) {
         const int np = (can_pair && is + 1 < group_size) ? 2 : 1;
         ShotCtx ctx[2];
         ctx[0] = make_ctx(is, 0, st);
@@ -628,8 +770,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             forward_fused(ctx[0]);
         } else {
             bool inl[2];
-            for (int k = 0; k < np; k++)
-                inl[k] = ctx[k].line.n > 0 && !(ctx[k].comps & 1) && get_kernel_option("line_fuse") != 0;
+            for (int k = 0; k < np; k++) inl[k] = forward_inline(ctx[k]);
             for (int it = 0; it <= nSteps - 2; it++)
                 for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
             for (int k = 0; k < np; k++)
@@ -656,15 +797,30 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             } else if (ctx[k].scratch) {
                 scratch_dumps(ctx[k]);
             }
-            if (withAdj) backward(ctx[k]);
+        }
+        if (withAdj) {
+            if (np == 2 && pair_bwd) {
+                backward(ctx, 2);
+            } else {
+                for (int k = 0; k < np; k++) backward(&ctx[k], 1);
+            }
         }
         is += np;
+    }
+    if (withAdj && grad_stf) {  // rows indexed by local shot position (libCUFD.cu:671-673)
+        h_gstf.resize((size_t)group_size * nSteps);
+        HIP_OK(hipMemcpy(h_gstf.data(), stf_grad_, h_gstf.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(grad_stf, h_gstf.data(), h_gstf.size() * sizeof(float), hipMemcpyDefault));
     }
 
     // ---- outputs ----
     if (withAdj) {
         const bool devL = is_device_ptr(grad_Lambda), devM = is_device_ptr(grad_Mu), devD = is_device_ptr(grad_Den);
         float *oL = devL ? grad_Lambda : grad_stage_, *oM = devM ? grad_Mu : grad_stage_ + dense, *oD = devD ? grad_Den : grad_stage_ + 2 * dense;
+        if (lane2_acc_used_) {  // shots that ran in the second backward lane
+            launch_add_inplace(st, acc_.lam, bwd2_acc_.lam, 5 * n);
+            launches_++;
+        }
         launch_finalize_gradients(st, g, md_, acc_, oL, oM, oD);
         launches_++;
         if (!devL) HIP_OK(hipMemcpyAsync(grad_Lambda, oL, dense * sizeof(float), hipMemcpyDefault, st));

@@ -39,6 +39,8 @@ class Session {
     template <class T> T *dalloc(size_t n);
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
     void ensure_lane2(bool with_frames);
+    void ensure_bwd_mem();
+    void ensure_bwd_lane2(hipStream_t st);
 
     struct ObsEntry {
         float *d_ett = nullptr;  // [nSteps][nrec]
@@ -65,7 +67,13 @@ class Session {
     size_t cells_ = 0, data_len_ = 0;
     float *lane2_state_ = nullptr, *frame2_ = nullptr, *syn2_ = nullptr, *res2_ = nullptr;  // second forward lane
     hipStream_t stream2_ = nullptr;
-    hipEvent_t ev_join_ = nullptr;
+    hipEvent_t ev_join_ = nullptr, ev_fwd_[2] = {nullptr, nullptr}, ev_bwd_[2] = {nullptr, nullptr};
+    PmlMem bwd_mem_{};  // backward-pass memory variables of the pipelined mode
+    size_t stf_grad_len_ = 0;
+    PmlMem bwd2_mem_{};  // second backward lane (pair_bwd)
+    Fields bwd2_adj_{};
+    ImgAcc bwd2_acc_{};
+    bool lane2_acc_used_ = false;
     float *state2_ = nullptr;  // second copy of the 5 fields + 4 stress-side memory variables (fused forward)
     int *rt_off_ = nullptr, *rt_cell_ = nullptr, *rt_rec_ = nullptr;
     int n_tiles_ = 0;
