@@ -5,9 +5,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one FWI gradient evaluation (`fwi_ops.backward`: forward + boundary-saving adjoint of ONE
-shot per GPU on the 2000x1000 model, 4000 time steps, plus -- for N > 1 -- the single RCCL all-reduce of
-[gLambda|gMu|gDen|misfit]).  Weak scaling: every rank owns one shot per step.  Inputs (model, source,
+One "step" = one FWI gradient evaluation (`fwi_ops.backward`: forward + boundary-saving adjoint of
+--shots-per-step (default 2) shots per GPU on the 2000x1000 model, 4000 time steps, plus -- for N > 1 -- the single
+RCCL all-reduce of [gLambda|gMu|gDen|misfit]).  Two shots per GPU per step because the session overlaps the forward
+passes of a pair of shots on two streams.  Weak scaling: every rank owns the same number of shots per step.  Inputs (model, source,
 observed data) are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
 
 cell-update = one grid cell advanced one time step by one propagator; a fwd+adj shot is

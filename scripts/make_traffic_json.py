@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""profiles/traffic.json from the two PMC summaries of the bench command (scripts/gpu_run7.sh):
+HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse(path, counter):
+    out, name = {}, None
+    for line in open(path):
+        m = re.match(r"^(\S.*?)\s+calls\s+\d+\s+avg", line)
+        if m:
+            name = m.group(1).strip()
+            continue
+        m = re.match(r"^\s+%s\s+([0-9.]+)" % counter, line)
+        if m and name:
+            out[name] = float(m.group(1))
+    return out
+
+
+fetch = parse(os.path.join(ROOT, "profiles", "r01_bench_pmc_fetch.txt"), "FETCH_SIZE")
+write = parse(os.path.join(ROOT, "profiles", "r01_bench_pmc_write.txt"), "WRITE_SIZE")
+keys = {"k_bwd_b": "k_bwd_b", "k_bwd_a": "k_bwd_a", "k_stress<true, true>": "k_stress_fwd_save", "k_velocity<true>": "k_velocity_fwd"}
+res = {"_how": "rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE on `python bench.py --steps 1 --warmup 0 --nsteps 400 "
+               "--no-cpu-baseline` (profiles/r01_bench_pmc_fetch.txt, r01_bench_pmc_write.txt); FETCH_SIZE doubled per the gfx950 "
+               "correction of MI355X_MICROARCH.md (calibrated on k_fwd_fused: 10 arrays x 9.19 MB = 91.9 MB compulsory vs 2 x 45.1 MB "
+               "counted), WRITE_SIZE as counted; KiB -> bytes.  Regenerate with scripts/make_traffic_json.py."}
+for pat, key in keys.items():
+    f = [v for k, v in fetch.items() if pat in k]
+    w = [v for k, v in write.items() if pat in k]
+    if not f or not w:
+        sys.exit("missing %s" % pat)
+    res[key + "_fetch_kib"] = f[0]
+    res[key + "_write_kib"] = w[0]
+    res[key + "_bytes_per_launch"] = int(round((2.0 * f[0] + w[0]) * 1024))
+json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k.endswith("per_launch")}, indent=1))

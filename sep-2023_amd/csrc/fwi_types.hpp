@@ -30,6 +30,7 @@ struct Grid {
     // launch tiling of the field kernels (filled by the launchers): gx x gy tiles of 64 columns x bz rows,
     // optionally renumbered so that each XCD (blockIdx % 8) owns a contiguous band of tiles
     int gx, gy, bz, xcd_remap;
+    int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
 };
 
 // Five wavefields (or their adjoint twins), each nzc*pitch floats.
@@ -47,6 +48,7 @@ struct PmlMem {
 // Media in internal layout, Pa.
 struct Media {
     const float *lam, *mu, *ave_mu, *byc_a, *byc_b;
+    const float *rho;  // density itself: the hot kernels rebuild byc_a / byc_b from it (option rho_fly) instead of streaming both
 };
 
 // 1-D C-PML profiles; z arrays have nzc entries, x arrays nx entries.  rK = 1/K.

@@ -48,6 +48,7 @@ int g_opt_pair_fwd = 1;             // 1: forward passes of two shots run concur
 int g_opt_pair_bwd = 0;             // 1: backward passes of two shots run concurrently (slower at 2000x1000: the pair does not fit the Infinity Cache)
 int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 never, 1 always, 2 only while two backward passes overlap
 int g_opt_early = 1;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
+int g_opt_rho_fly = 1;              // buoyancy averages rebuilt from the density: bit 0 forward velocity kernel (+3.6 %), bit 1 backward kernels (-1.2 %)
 int g_opt_pipe_bwd = 0;             // 1: backward of shot k overlaps the forward of shot k+1 (session.cpp)
 int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
@@ -210,6 +211,22 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
 // ---------------------------------------------------------------------------------------------
 // velocity update
 // ---------------------------------------------------------------------------------------------
+// Buoyancy averages of cell i: byc_a = 2/(rho(z+1,x)+rho(z,x)), byc_b = 2/(rho(z,x+1)+rho(z,x))  (aveBycInit,
+// utilities.cu:139-152).  rho_fly: rebuilt from the density -- one array streamed (+ two neighbour taps that hit the
+// cache) instead of two; the IEEE float quotient equals the reference's (float)(2.0 / (double)sum) bit for bit
+// (a double quotient of two floats rounds to float exactly like the float division).  Valid on [2, n-3]^2 of the
+// padded grid, which contains every cell the velocity-type kernels update.
+__device__ __forceinline__ void buoyancies(const Grid &g, const Media &md, size_t i, float &ba, float &bb) {
+    if (g.rho_fly) {
+        const float r0 = md.rho[i];
+        ba = 2.0f / (md.rho[i + g.pitch] + r0);
+        bb = 2.0f / (md.rho[i + 1] + r0);
+    } else {
+        ba = md.byc_a[i];
+        bb = md.byc_b[i];
+    }
+}
+
 template <bool FWD, bool NT = false>
 __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
@@ -225,7 +242,9 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
         float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
         float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
         float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
-        const float vz0 = f.vz[i], vx0 = f.vx[i], ba = md.byc_a[i], bb = md.byc_b[i];  // all loads before the first store
+        const float vz0 = f.vz[i], vx0 = f.vx[i];  // all loads before the first store
+        float ba, bb;
+        buoyancies(g, md, i, ba, bb);
         if (in_pml_z(g, z)) {
             float p = pc.b_zh[z] * m.dszz_dz[i] + pc.a_zh[z] * dszz_dz;
             m.dszz_dz[i] = p;
@@ -257,8 +276,10 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
             const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
             const float g_a = acc_load<NT>(acc.a + i), g_b = acc_load<NT>(acc.b + i), avz = adj.vz[i], avx = adj.vx[i];
-            vz = f.vz[i] - (dszz_dz + dsxz_dx) * md.byc_a[i] * g.dt;
-            vx = f.vx[i] - (dsxz_dz + dsxx_dx) * md.byc_b[i] * g.dt;
+            float ba, bb;
+            buoyancies(g, md, i, ba, bb);
+            vz = f.vz[i] - (dszz_dz + dsxz_dx) * ba * g.dt;
+            vx = f.vx[i] - (dsxz_dz + dsxx_dx) * bb * g.dt;
             // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
             acc_store<NT>(acc.a + i, g_a + -avz * (dszz_dz + dsxz_dx) * g.dt);
             acc_store<NT>(acc.b + i, g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt);
@@ -390,7 +411,7 @@ __device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell
     q.vx_zm1 = f.vx[i - P]; q.vx_0 = f.vx[i]; q.vx_zp1 = f.vx[i + P]; q.vx_zp2 = f.vx[i + 2 * P];
     q.vx_xm2 = f.vx[i - 2]; q.vx_xm1 = f.vx[i - 1]; q.vx_xp1 = f.vx[i + 1];
     q.sxz = f.sxz[i]; q.sxx = f.sxx[i]; q.szz = f.szz[i];
-    q.ba = md.byc_a[i]; q.bb = md.byc_b[i];
+    buoyancies(g, md, i, q.ba, q.bb);
     q.rKx = pc.rK_x[x]; q.rKxh = pc.rK_xh[x]; q.rKz = pc.rK_z[z]; q.rKzh = pc.rK_zh[z];
     return q;
 }
@@ -522,7 +543,7 @@ __device__ __forceinline__ Fields fields_of(float *b, size_t n) { return Fields{
 __device__ __forceinline__ PmlMem mem_of(float *b, size_t n) {
     return PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
 }
-__device__ __forceinline__ Media media_of(const float *b, size_t n) { return Media{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
+__device__ __forceinline__ Media media_of(const float *b, size_t n) { return Media{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n}; }
 __device__ __forceinline__ ImgAcc acc_of(float *b, size_t n) { return ImgAcc{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
 __device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int nzc, int nx) {
     return PmlCoef{cz, cz + nzc, cz + 2 * nzc, cz + 3 * nzc, cz + 4 * nzc, cz + 5 * nzc,
@@ -644,7 +665,7 @@ __global__ void k_transpose(const float *__restrict__ in, float *__restrict__ ou
 __global__ void k_model_prep(Grid g, const float *__restrict__ Lam_in, const float *__restrict__ Mu_in,
                              const float *__restrict__ Den_in, float *__restrict__ lam, float *__restrict__ mu,
                              float *__restrict__ ave_mu, float *__restrict__ byc_a, float *__restrict__ byc_b,
-                             unsigned int *__restrict__ cp2_max_bits) {
+                             float *__restrict__ rho, unsigned int *__restrict__ cp2_max_bits) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int z = blockIdx.y * blockDim.y + threadIdx.y;
     float cp2 = 0.0f;
@@ -658,6 +679,7 @@ __global__ void k_model_prep(Grid g, const float *__restrict__ Lam_in, const flo
             const size_t i = (size_t)z * g.pitch + x;
             lam[i] = L;
             mu[i] = M;
+            rho[i] = D;
             float am = 0.0f, ba = 1.0f / 1000.0f, bb = 1.0f / 1000.0f;  // Model.cu:67,72-73
             // averages exist on [2, n-3] of the FULL padded grid (utilities.cu:129,146); rows >= nzc are
             // never read by any kernel.
@@ -745,12 +767,13 @@ __global__ void k_finalize_gradients(Grid g, Media md, ImgAcc acc, float *__rest
 // =============================================================================================
 // launchers
 // =============================================================================================
-static inline Grid tiled(const Grid &g0) {
+static inline Grid tiled(const Grid &g0, int rho_bit = -1) {
     Grid g = g0;
     g.bz = g_opt_bz;
     g.gx = (g.nx + BX - 1) / BX;
     g.gy = (g.nzc + g.bz - 1) / g.bz;
     g.xcd_remap = g_opt_xcd_remap;
+    g.rho_fly = rho_bit < 0 ? 0 : (g_opt_rho_fly >> rho_bit) & 1;
     return g;
 }
 static inline dim3 field_grid(const Grid &g) {
@@ -773,6 +796,7 @@ int get_kernel_option(const char *name) {
     if (n == "pair_fwd") return g_opt_pair_fwd;
     if (n == "pipe_bwd") return g_opt_pipe_bwd;
     if (n == "pair_bwd") return g_opt_pair_bwd;
+    if (n == "rho_fly") return g_opt_rho_fly;
     if (n == "early") return g_opt_early;
     if (n == "acc_nt") return g_opt_acc_nt;
     return -1;
@@ -790,6 +814,7 @@ int set_kernel_option(const char *name, int value) {
     if (n == "pair_fwd") { g_opt_pair_fwd = value ? 1 : 0; return 0; }
     if (n == "pipe_bwd") { g_opt_pipe_bwd = value ? 1 : 0; return 0; }
     if (n == "pair_bwd") { g_opt_pair_bwd = value ? 1 : 0; return 0; }
+    if (n == "rho_fly" && value >= 0 && value <= 3) { g_opt_rho_fly = value; return 0; }
     if (n == "early" && value >= 0 && value <= 3) { g_opt_early = value; return 0; }
     if (n == "acc_nt" && value >= 0 && value <= 2) { g_opt_acc_nt = value; return 0; }
     return -1;
@@ -809,7 +834,7 @@ void launch_stress_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media
 }
 
 void launch_velocity_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc) {
-    const Grid g = tiled(g0);
+    const Grid g = tiled(g0, 0);
     Fields none{};
     ImgAcc na{};
     hipLaunchKernelGGL((k_velocity<true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, (const float *)nullptr,
@@ -818,7 +843,7 @@ void launch_velocity_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Med
 
 void launch_velocity_rev(hipStream_t st, const Grid &g0, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
                          int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
-    const Grid g = tiled(g0);
+    const Grid g = tiled(g0, 1);
     PmlMem nm{};
     hipLaunchKernelGGL((k_velocity<false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src, x_src,
                        src_rxz, stf_grad_it, adj, acc);
@@ -838,20 +863,20 @@ void launch_velocity_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, M
 }
 
 void launch_stress_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Media md, PmlCoef pc) {
-    const Grid g = tiled(g0);
+    const Grid g = tiled(g0, 1);
     hipLaunchKernelGGL(k_stress_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
 void launch_bwd_velocity(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
                          int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
-    const Grid g = tiled(g0);
+    const Grid g = tiled(g0, 1);
     hipLaunchKernelGGL(k_bwd_velocity, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it,
                        adj, acc, lr);
 }
 
 void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
                        int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const Grid g = tiled(g0);
+    const Grid g = tiled(g0, 1);
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
         hipExtLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, f, m, md, pc, frame_t, z_src,
                               x_src, src_amp, adj, acc);
@@ -861,7 +886,7 @@ void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media
 
 void launch_bwd_a(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
                   ImgAcc acc, bool acc_nt) {
-    const Grid g = tiled(g0);
+    const Grid g = tiled(g0, 1);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
     const bool early = (g_opt_early & 1) != 0;
     auto k = acc_nt ? (early ? k_bwd_a<true, true> : k_bwd_a<true, false>) : (early ? k_bwd_a<false, true> : k_bwd_a<false, false>);
@@ -916,9 +941,9 @@ void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int
 }
 
 void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const float *Mu_in, const float *Den_in,
-                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, unsigned int *cp2_max_bits) {
+                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, float *rho, unsigned int *cp2_max_bits) {
     hipLaunchKernelGGL(k_model_prep, dim3((g.nx + 63) / 64, (g.nz + 3) / 4), dim3(64, 4), 0, st, g, Lam_in, Mu_in, Den_in,
-                       lam, mu, ave_mu, byc_a, byc_b, cp2_max_bits);
+                       lam, mu, ave_mu, byc_a, byc_b, rho, cp2_max_bits);
 }
 
 void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,

@@ -39,7 +39,7 @@ void launch_residual(hipStream_t st, const float *obs, const float *syn, float *
                      double *sumsq);
 void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);
 void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const float *Mu_in, const float *Den_in,
-                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, unsigned int *cp2_max_bits);
+                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, float *rho, unsigned int *cp2_max_bits);
 void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
                                float *gDen);
 

@@ -102,9 +102,9 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     mem2_.dvz_dx = state2_ + 6 * n;
     mem2_.dvx_dz = state2_ + 7 * n;
     mem2_.dvx_dx = state2_ + 8 * n;
-    media_ = dalloc<float>(5 * n);
-    HIP_OK(hipMemset(media_, 0, 5 * n * sizeof(float)));
-    md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n};
+    media_ = dalloc<float>(6 * n);
+    HIP_OK(hipMemset(media_, 0, 6 * n * sizeof(float)));
+    md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n};
     acc_buf_ = dalloc<float>(5 * n);
     acc_ = ImgAcc{acc_buf_, acc_buf_ + n, acc_buf_ + 2 * n, acc_buf_ + 3 * n, acc_buf_ + 4 * n};
     const size_t dense = (size_t)par.nz * (size_t)par.nx;
@@ -342,7 +342,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     if (!is_device_ptr(Mu)) { HIP_OK(hipMemcpyAsync(in_stage_ + dense, Mu, dense * sizeof(float), hipMemcpyDefault, st)); dM = in_stage_ + dense; }
     if (!is_device_ptr(Den)) { HIP_OK(hipMemcpyAsync(in_stage_ + 2 * dense, Den, dense * sizeof(float), hipMemcpyDefault, st)); dD = in_stage_ + 2 * dense; }
     HIP_OK(hipMemsetAsync(cp2_bits_, 0, sizeof(unsigned int), st));
-    launch_model_prep(st, g, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, cp2_bits_);
+    launch_model_prep(st, g, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n, cp2_bits_);
     launches_++;
     {
         unsigned int bits = 0;
