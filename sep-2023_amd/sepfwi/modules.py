@@ -1,6 +1,7 @@
 """Parameterisation modules: user parameters -> pad / mask -> (Lambda[MPa], Mu[MPa], Den) -> FWIFunction.
 
-These are the pure-torch CALLERS of the operator boundary (reference: FWI_ops.py:66-330).  Same class
+These are the pure-torch CALLERS of the operator boundary (reference: FWI_ops.py:66-330).  They work on CPU
+tensors exactly like the reference and, unlike it, on HIP tensors too (device-resident iteration).  Same class
 names, constructor signatures, attribute names (parameters `Vp`/`Vs`/`Den` ..., buffers `*_ref`, `Bounds`,
 `Mask`) and forward(Shot_ids, ngpu) contract, so obj_wrapper.PyTorchObjective and the experiment scripts
 work unchanged.  One generic base replaces the reference's copy-per-parameterisation.
@@ -35,8 +36,12 @@ class _MaskedTriple(nn.Module):
             else:
                 setattr(self, name, t)
         if Mask is None:
-            Mask = torch.ones((self.nz + 2 * self.nPml + self.nPad, self.nx + 2 * self.nPml), dtype=torch.float32)
-        self.Mask = Mask
+            Mask = torch.ones((self.nz + 2 * self.nPml + self.nPad, self.nx + 2 * self.nPml), dtype=torch.float32,
+                              device=padded[0].device)
+        # a buffer (the reference keeps a plain attribute, FWI_ops.py:98-103) so that module.to(device) moves it with
+        # the parameters: with HIP tensors the whole chain pad -> mask -> Lame map -> propagator -> chain rule stays
+        # in HBM; only SciPy's flat vector crosses PCIe
+        self.register_buffer("Mask", Mask.to(padded[0].device))
         self.Stf = Stf
         self.para_fname = opt["para_fname"]
 

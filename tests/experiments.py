@@ -78,24 +78,27 @@ def setup(exp, workdir):
 
 
 def run_iterate0(exp, workdir, ngpu=1, device=None):
-    """-> dict(f, ginf, grads{name: array}) at the initial model (what L-BFGS-B prints at iterate 0)."""
+    """-> dict(f, ginf, grads{name: array}) at the initial model (what L-BFGS-B prints at iterate 0).
+    device: None/"cpu" = the reference's host tensors; "cuda" = every tensor of the chain lives in HBM."""
     from sepfwi import modules as M
     from sepfwi import utils as ft
     from sepfwi.obj_wrapper import PyTorchObjective
+    dev = torch.device(device or "cpu")
     su = setup(exp, workdir)
     (vp_t, vs_t, rho_t), (vp_i, vs_i, rho_i) = models(exp)
-    pad = lambda a: torch.tensor(ft.padding_numpy_array(a, nPml, su["nPad"]), dtype=torch.float32)
-    M.FWI_obscalc(pad(vp_t), pad(vs_t), pad(rho_t), su["Stf"], su["para_fname"])(su["Shot_ids"], ngpu=ngpu)
-    T = lambda a: torch.tensor(a, dtype=torch.float32, requires_grad=True)
+    pad = lambda a: torch.tensor(ft.padding_numpy_array(a, nPml, su["nPad"]), dtype=torch.float32, device=dev)
+    Stf, Mask = su["Stf"].to(dev), su["Mask"].to(dev)
+    M.FWI_obscalc(pad(vp_t), pad(vs_t), pad(rho_t), Stf, su["para_fname"])(su["Shot_ids"], ngpu=ngpu)
+    T = lambda a: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True)
     if exp == "001":
-        fwi = M.FWI(T(vp_i), T(vs_i), T(rho_i), su["Stf"], su["opt"], Mask=su["Mask"])
+        fwi = M.FWI(T(vp_i), T(vs_i), T(rho_i), Stf, su["opt"], Mask=Mask)
     elif exp == "002":
         lam_i = rho_i * (vp_i ** 2 - 2.0 * vs_i ** 2) / 1e6          # Main-002:119-120
         mu_i = rho_i * vs_i ** 2 / 1e6
-        fwi = M.FWI_Lame_Den(T(lam_i), T(mu_i), T(rho_i), su["Stf"], su["opt"], Mask=su["Mask"])
+        fwi = M.FWI_Lame_Den(T(lam_i), T(mu_i), T(rho_i), Stf, su["opt"], Mask=Mask)
     else:
         vpk, vsk = vp_i / 1e3, vs_i / 1e3                              # Main-003:119-122
-        fwi = M.FWI_IP_IS_Den(T(vpk * rho_i), T(vsk * rho_i), T(rho_i), su["Stf"], su["opt"], Mask=su["Mask"])
+        fwi = M.FWI_IP_IS_Den(T(vpk * rho_i), T(vsk * rho_i), T(rho_i), Stf, su["opt"], Mask=Mask)
     obj = PyTorchObjective(fwi, lambda: fwi(su["Shot_ids"], ngpu=ngpu))
     jac = obj.jac            # the reference's quirk: cache() shadows .jac with the array (obj_wrapper.py:86)
     f = obj.fun(obj.x0)
