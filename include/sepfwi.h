@@ -61,6 +61,9 @@ int sepfwi_device_count(void);
  *   para_fname   one-line JSON written by fwi_utils.paraGen (fwi_utils.py:46-83); names the survey
  *                JSON (fwi_utils.py:87-124) and the data directory holding
  *                Shot_{pr,vx,vz,ett}{id}.bin, float32 [nrec][nSteps] (libCUFD.cu:216-223,755-769).
+ *                One optional key beyond the reference's schema: "das_fiber": "horizontal" (default: ett = exx,
+ *                recording_exx / res_injection_exx) or "vertical" (ett = ezz, recording_ezz / res_injection_ezz,
+ *                Src/utilities.cu:620-641, which the reference reaches only through a source edit).
  *
  * Unlike the reference, device state (fields, PML profiles, boundary buffers, observed data) is kept
  * in a per-(para_fname, gpu_id) session between calls; sepfwi_release_all() frees it.

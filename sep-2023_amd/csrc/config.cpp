@@ -37,6 +37,13 @@ Params parse_params(const std::string &text) {
     if (j.has("if_src_update")) p.if_src_update = j.at("if_src_update").as_bool("if_src_update");
     if (j.has("if_cross_misfit")) p.if_cross_misfit = j.at("if_cross_misfit").as_bool("if_cross_misfit");
     p.has_filter = j.has("filter");
+    if (j.has("das_fiber")) {
+        const std::string f = j.at("das_fiber").as_string("das_fiber");
+        if (f == "vertical")
+            p.fiber = 1;
+        else if (f != "horizontal")
+            throw std::runtime_error("parameter JSON: das_fiber must be \"horizontal\" or \"vertical\"");
+    }
     if (p.nz <= 0 || p.nx <= 0 || p.nSteps < 2 || p.nPml < 2 || p.nPad < 0)
         throw std::runtime_error("parameter JSON: need nz,nx > 0, nSteps >= 2, nPoints_pml >= 2, nPad >= 0");
     if (p.nz - p.nPad - 2 * p.nPml < 6 || p.nx - 2 * p.nPml < 6)

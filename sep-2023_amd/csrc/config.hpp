@@ -13,6 +13,9 @@ struct Params {
     int nSteps = 0, nPml = 0, nPad = 0;
     std::string survey_fname, data_dir_name, scratch_dir_name;
     bool if_win = false, if_src_update = false, if_cross_misfit = false, has_filter = false;
+    // optional key "das_fiber": "horizontal" (default; recording_exx / res_injection_exx, libCUFD.cu:325,607) or
+    // "vertical" (recording_ezz / res_injection_ezz, utilities.cu:620-641 -- in the reference a source edit)
+    int fiber = 0;
 };
 
 struct Shot {

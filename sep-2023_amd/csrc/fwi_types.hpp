@@ -30,6 +30,7 @@ struct Grid {
     // launch tiling of the field kernels (filled by the launchers): gx x gy tiles of 64 columns x bz rows,
     // optionally renumbered so that each XCD (blockIdx % 8) owns a contiguous band of tiles
     int gx, gy, bz, xcd_remap;
+    int fiber;    // DAS fibre direction: 0 horizontal (exx), 1 vertical (ezz)
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
 };
 

@@ -598,27 +598,36 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
 // ---------------------------------------------------------------------------------------------
 __global__ void k_record(Grid g, Fields f, int nrec, const int *__restrict__ rec_idx /* z*pitch+x */,
                          float *__restrict__ d_pr, float *__restrict__ d_vx, float *__restrict__ d_vz,
-                         float *__restrict__ d_ett, int comps) {
+                         float *__restrict__ d_ett, int comps, int fiber) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const int i = rec_idx[r];
     if (comps & 1) d_pr[r] = f.szz[i] + f.sxx[i];
     const float vx = f.vx[i];
     if (comps & 2) d_vx[r] = vx;
-    if (comps & 4) d_vz[r] = f.vz[i];
-    if (comps & 8) d_ett[r] = vx - f.vx[i - 1];  // not divided by dx (utilities.cu:600-601)
+    const float vz = f.vz[i];
+    if (comps & 4) d_vz[r] = vz;
+    // axial strain over one cell, not divided by the spacing (utilities.cu:600-601): exx for a horizontal fibre,
+    // ezz (recording_ezz, utilities.cu:620-629) for a vertical one
+    if (comps & 8) d_ett[r] = fiber ? vz - f.vz[i - g.pitch] : vx - f.vx[i - 1];
 }
 
 // res_injection_exx: vx_adj(z,x) += r ; vx_adj(z,x-1) -= r.  Adjacent channels share cells, so the
 // two statements are applied through float atomics (the reference's plain +=/-= is racy there,
 // utilities.cu:613-614).  Atomic order only permutes two adds per cell.
-__global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, const float *__restrict__ res_t) {
+__global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, const float *__restrict__ res_t,
+                         int down /* 0: horizontal fibre, else the pitch: vertical fibre (res_injection_ezz, utilities.cu:632-641) */) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const int i = rec_idx[r];
     const float v = res_t[r];
-    atomicAdd(&adj.vx[i], v);
-    atomicAdd(&adj.vx[i - 1], -v);
+    if (down) {
+        atomicAdd(&adj.vz[i], v);
+        atomicAdd(&adj.vz[i - down], -v);
+    } else {
+        atomicAdd(&adj.vx[i], v);
+        atomicAdd(&adj.vx[i - 1], -v);
+    }
 }
 
 // residual r = obs - syn (time sample 0 forced to 0) and sum r^2, all time-major [it][rec].
@@ -919,12 +928,12 @@ void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int 
                    float *d_vz, float *d_ett, int comps) {
     if (nrec <= 0) return;
     hipLaunchKernelGGL(k_record, dim3((nrec + 255) / 256), dim3(256), 0, st, g, f, nrec, rec_idx, d_pr, d_vx, d_vz, d_ett,
-                       comps);
+                       comps, g.fiber);
 }
 
-void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t) {
+void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t, int down) {
     if (nrec <= 0) return;
-    hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t);
+    hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t, down);
 }
 
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,

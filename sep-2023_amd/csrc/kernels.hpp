@@ -34,7 +34,7 @@ void launch_fwd_fused(hipStream_t st, const Grid &g, const FwdFusedArgs &a, int 
 void launch_fwd_march(hipStream_t st, const Grid &g, const FwdFusedArgs &a, LineRec lr, int xcd_remap);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps);
-void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t);
+void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t, int down = 0);
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
                      double *sumsq);
 void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);

@@ -73,6 +73,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     g.nx = par.nx;
     g.nzc = par.nz - par.nPad;
     g.pitch = ((par.nx + 63) / 64) * 64;
+    g.fiber = par.fiber;
     g.nPml = par.nPml;
     g.zmax = g.nzc - 1 - par.nPml;
     g.xmax = par.nx - 1 - par.nPml;
@@ -147,7 +148,8 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
             if (sh.z_src < 2 || sh.z_src > g.nzc - 3 || sh.x_src < 2 || sh.x_src > g.nx - 3)
                 throw std::runtime_error("survey: source of shot " + std::to_string(i) + " lies outside the computed grid");
             for (int r = 0; r < sh.nrec; r++) {
-                if (sh.z_rec[r] < 0 || sh.z_rec[r] >= g.nzc || sh.x_rec[r] < 1 || sh.x_rec[r] >= g.nx)
+                // the axial-strain difference reaches one cell to the left (horizontal fibre) or up (vertical fibre)
+                if (sh.z_rec[r] < (par.fiber ? 1 : 0) || sh.z_rec[r] >= g.nzc || sh.x_rec[r] < (par.fiber ? 0 : 1) || sh.x_rec[r] >= g.nx)
                     throw std::runtime_error("survey: receiver " + std::to_string(r) + " of shot " + std::to_string(i) +
                                              " lies outside the grid");
                 idx[(size_t)rec_off_[i] + r] = sh.z_rec[r] * g.pitch + sh.x_rec[r];
@@ -397,7 +399,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         float *frame, *syn, *res;
         hipStream_t st;
     };
-    const int fuse_fwd = get_kernel_option("fwd_fuse");
+    const int fuse_fwd = par_.fiber ? 0 : get_kernel_option("fwd_fuse");  // the fused forward steps sample exx themselves
     if (withAdj) {  // source-time-function gradients of all shots of the call, one row each
         const size_t need = (size_t)group_size * nSteps;
         if (need > stf_grad_len_) {
@@ -433,7 +435,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         c.comps = if_res ? (c.scratch ? 9 : 8) : 15;
         // horizontal line of consecutive channels inside the computed region?
         const Shot &sh = *c.sh;
-        bool is_line = c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
+        bool is_line = par_.fiber == 0 && c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
         for (int r = 1; r < c.nrec && is_line; r++) is_line = (sh.z_rec[r] == sh.z_rec[0] && sh.x_rec[r] == sh.x_rec[0] + r);
         if (is_line) {
             c.line.z = sh.z_rec[0];
@@ -642,18 +644,18 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         if (fuse_bwd == 2) {
             launch_bwd_a(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, L.adj, L.acc, L.nt);
             launch_bwd_b(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1, L.nt);
-            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t);
+            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
             launches_ += inj_inl ? 2 : 3;
         } else if (fuse_bwd == 1) {
             launch_bwd_velocity(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc, lr);
-            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t);
+            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
             launch_bwd_stress(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc, e0, e1);
             launches_ += 3;
         } else {
             launch_velocity_rev(L.s, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
             launch_stress_rev(L.s, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
             launch_velocity_adj(L.s, g, L.adj, L.bm, md_, pc_);
-            launch_inject(L.s, L.adj, c.nrec, c.rec, res_t);
+            launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
             launch_stress_adj(L.s, g, L.adj, L.bm, md_, pc_);
             launches_ += 5;
         }

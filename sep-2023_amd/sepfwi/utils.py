@@ -34,8 +34,13 @@ def padding(cp, cs, den, nz_orig, nx_orig, nz, nx, nPml, nPad):
 
 
 def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir_name,
-            if_win=False, filter_para=None, if_src_update=False, scratch_dir_name="", if_cross_misfit=False):
-    """Write the one-line parameter JSON (schema of fwi_utils.py:46-83; nz, nx are the PADDED sizes)."""
+            if_win=False, filter_para=None, if_src_update=False, scratch_dir_name="", if_cross_misfit=False,
+            das_fiber="horizontal"):
+    """Write the one-line parameter JSON (schema of fwi_utils.py:46-83; nz, nx are the PADDED sizes).
+    das_fiber (extension): "horizontal" = axial strain exx = vx(x) - vx(x-1), the reference's live
+    choice; "vertical" = ezz = vz(z) - vz(z-1) (recording_ezz / res_injection_ezz, Src/utilities.cu:620-641, which the
+    reference only reaches by editing libCUFD.cu).  The key is written only when it is not the default, so default
+    files stay byte-identical to the reference's."""
     para = {"nz": int(nz), "nx": int(nx), "dz": dz, "dx": dx, "nSteps": int(nSteps), "dt": float(dt),
             "f0": f0, "nPoints_pml": int(nPml), "nPad": int(nPad)}
     if if_win:
@@ -49,6 +54,10 @@ def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname
     os.makedirs(data_dir_name, exist_ok=True)
     if if_cross_misfit:
         para["if_cross_misfit"] = True
+    if das_fiber != "horizontal":
+        if das_fiber != "vertical":
+            raise ValueError("das_fiber must be 'horizontal' or 'vertical'")
+        para["das_fiber"] = das_fiber
     if scratch_dir_name != "":
         para["scratch_dir_name"] = scratch_dir_name
         os.makedirs(scratch_dir_name, exist_ok=True)

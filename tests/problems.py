@@ -17,7 +17,7 @@ def smooth_random(rng, shape, lo, hi, passes=8):
 
 
 def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, dt=1.0e-3, f0=25.0,
-                 hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None, src_x=None):
+                 hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None, src_x=None, das_fiber="horizontal"):
     """Writes para/survey JSON under workdir and returns everything a test needs.
     Models: `true` (with anomalies) and `init` (smooth), both (nz, nx) float32, plus padded versions."""
     rng = np.random.default_rng(seed)
@@ -45,11 +45,14 @@ def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, 
     para_fname = os.path.join(workdir, "para_file.json")
     survey_fname = os.path.join(workdir, "survey_file.json")
     data_dir = os.path.join(workdir, "Data")
-    ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir)
+    ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir, das_fiber=das_fiber)
     src_x = np.linspace(6, nx - 7, nshots).round().astype(int) if src_x is None else np.asarray(src_x, dtype=int)
     src_zs = np.full(nshots, src_z, dtype=int)
     rec_x = np.arange(4, nx - 4, nrec_stride).astype(int)
     rec_zs = np.full(rec_x.shape, (nz - 6) if rec_z is None else rec_z, dtype=int)
+    if das_fiber == "vertical":   # a borehole fibre: one column, consecutive depths
+        rec_zs = np.arange(4, nz - 4, nrec_stride).astype(int)
+        rec_x = np.full(rec_zs.shape, nx // 2 + 3, dtype=int)
     ft.surveyGen(src_zs, src_x, rec_zs, rec_x, survey_fname)
     stf = ft.sourceGene(f0, nSteps, dt)
     Stf = torch.tensor(stf, dtype=torch.float32).repeat(nshots, 1)

@@ -146,7 +146,7 @@ def test_fwifunction_contract_and_module_chain_rule(monkeypatch, tmp_path):
     mask = torch.zeros(pb["nz_pad"], pb["nx_pad"]); mask[4:16, 4:18] = 1.0
     fwi = M.FWI(vp, vs, rho, pb["Stf"], pb["opt"], Mask=mask)
     assert [n for n, _ in fwi.named_parameters()] == ["Vp", "Vs", "Den"]
-    assert set(dict(fwi.named_buffers())) == {"Vp_ref", "Vs_ref", "Den_ref"}
+    assert set(dict(fwi.named_buffers())) == {"Vp_ref", "Vs_ref", "Den_ref", "Mask"}   # Mask: a buffer so .to(device) moves it
     loss = fwi(pb["Shot_ids"], ngpu=1)
     assert float(loss) == 3.5
     (10.0 * loss).backward()      # grad_misfit is ignored by the reference's Function (FWI_ops.py:54-63)
@@ -174,3 +174,17 @@ def test_obj_wrapper_roundtrip(monkeypatch, tmp_path):
     assert obj.fun(obj.x0) == 3.5
     g = jac(obj.x0)
     assert g.dtype == np.float64 and g.shape == obj.x0.shape and np.all(np.isfinite(g))
+
+
+def test_das_fiber_key_is_optional_and_validated(tmp_path):
+    """The fibre-direction extension does not change default files (byte-identical to the reference's paraGen output)
+    and rejects anything but the two directions, on the Python and on the C side."""
+    import json
+    from sepfwi import utils as ft
+    a, b = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 12, a, "s.json", str(tmp_path / "D"))
+    ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 12, b, "s.json", str(tmp_path / "D"), das_fiber="vertical")
+    assert "das_fiber" not in json.load(open(a))
+    assert json.load(open(b))["das_fiber"] == "vertical"
+    with pytest.raises(ValueError):
+        ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 12, a, "s.json", str(tmp_path / "D"), das_fiber="diagonal")
