@@ -938,9 +938,9 @@ void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, con
 
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
                      double *sumsq) {
+    if (n <= 0) return;  // a shot without receivers contributes nothing
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, st, obs, syn, res, nrec, n, sumsq);
 }
 

@@ -276,6 +276,7 @@ void Session::drop_observed() {
 
 // Observed axial-strain gather of one shot, time-major in HBM; (re)loaded when the file changed.
 const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
+    if (nrec <= 0) return nullptr;  // nothing to compare against
     const std::string fn = shot_file(par_, 3, shot_id);
     struct stat sb;
     if (stat(fn.c_str(), &sb) != 0) throw IoError("cannot read observed data '" + fn + "'");  // utilities.cu:12-16
