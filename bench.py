@@ -6,9 +6,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one FWI gradient evaluation (`fwi_ops.backward`: forward + boundary-saving adjoint of
---shots-per-step (default 2) shots per GPU on the 2000x1000 model, 4000 time steps, plus -- for N > 1 -- the single
-RCCL all-reduce of [gLambda|gMu|gDen|misfit]).  Two shots per GPU per step because the session overlaps the forward
-passes of a pair of shots on two streams.  Weak scaling: every rank owns the same number of shots per step.  Inputs (model, source,
+--shots-per-step (default 3) shots per GPU on the 2000x1000 model, 4000 time steps, plus -- for N > 1 -- the single
+RCCL all-reduce of [gLambda|gMu|gDen|misfit]).  Three shots per GPU per step because the session overlaps the forward
+passes of up to three shots on three streams.  Weak scaling: every rank owns the same number of shots per step.  Inputs (model, source,
 observed data) are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
 
 cell-update = one grid cell advanced one time step by one propagator; a fwd+adj shot is
@@ -120,8 +120,8 @@ def main():
     ap.add_argument("--nsteps", type=int, default=4000, help="time steps per shot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="fwdadj", choices=["fwdadj", "fwd"])
-    ap.add_argument("--shots-per-step", type=int, default=2,
-                    help="shots each GPU processes per step (2: the forward passes of the pair overlap on two streams)")
+    ap.add_argument("--shots-per-step", type=int, default=3,
+                    help="shots each GPU processes per step (3: the forward passes of the three overlap on three streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -17,7 +17,7 @@ import bench
 from sepfwi import _native, fwi_ops
 
 
-DEFAULTS = dict(bz=1, xcd_remap=1, bwd_fuse=2, fwd_fuse=0, line_fuse=1, pair_fwd=1, pair_bwd=0, acc_nt=2, pipe_bwd=0, early=1, rho_fly=1)
+DEFAULTS = dict(bz=1, xcd_remap=1, bwd_fuse=2, fwd_fuse=0, line_fuse=1, pair_fwd=1, pair_bwd=0, acc_nt=2, pipe_bwd=0, early=1, rho_fly=1, fwd_lanes=3)
 
 
 def main():
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--nz", type=int, default=1000)
     ap.add_argument("--nx", type=int, default=2000)
-    ap.add_argument("--shots", type=int, default=2)
+    ap.add_argument("--shots", type=int, default=3)
     a = ap.parse_args()
     L = _native.lib()
     dev = torch.device("cuda", 0)

@@ -44,7 +44,8 @@ int g_opt_bwd_fuse = 2;             // backward step: 0 four kernels, 1 {vel,vel
 int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip)
 int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
 int g_opt_march_waves = 1280;       // target number of waves of the z-marching forward kernel
-int g_opt_pair_fwd = 1;             // 1: forward passes of two shots run concurrently on two streams
+int g_opt_pair_fwd = 1;             // 1: forward passes of several shots run concurrently, one stream each
+int g_opt_fwd_lanes = 3;            // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
 int g_opt_pair_bwd = 0;             // 1: backward passes of two shots run concurrently (slower at 2000x1000: the pair does not fit the Infinity Cache)
 int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 never, 1 always, 2 only while two backward passes overlap
 int g_opt_early = 1;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
@@ -803,6 +804,7 @@ int get_kernel_option(const char *name) {
     if (n == "probe") return g_opt_probe;
     if (n == "march_waves") return g_opt_march_waves;
     if (n == "pair_fwd") return g_opt_pair_fwd;
+    if (n == "fwd_lanes") return g_opt_fwd_lanes;
     if (n == "pipe_bwd") return g_opt_pipe_bwd;
     if (n == "pair_bwd") return g_opt_pair_bwd;
     if (n == "rho_fly") return g_opt_rho_fly;
@@ -821,6 +823,7 @@ int set_kernel_option(const char *name, int value) {
     if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
     if (n == "march_waves" && value >= 1) { g_opt_march_waves = value; return 0; }
     if (n == "pair_fwd") { g_opt_pair_fwd = value ? 1 : 0; return 0; }
+    if (n == "fwd_lanes" && value >= 1 && value <= 4) { g_opt_fwd_lanes = value; return 0; }
     if (n == "pipe_bwd") { g_opt_pipe_bwd = value ? 1 : 0; return 0; }
     if (n == "pair_bwd") { g_opt_pair_bwd = value ? 1 : 0; return 0; }
     if (n == "rho_fly" && value >= 0 && value <= 3) { g_opt_rho_fly = value; return 0; }

@@ -201,12 +201,14 @@ Session::~Session() {
         if (ev_fwd_[k]) (void)hipEventDestroy(ev_fwd_[k]);
         if (ev_bwd_[k]) (void)hipEventDestroy(ev_bwd_[k]);
     }
-    if (lane2_state_) (void)hipFree(lane2_state_);
-    if (frame2_) (void)hipFree(frame2_);
-    if (syn2_) (void)hipFree(syn2_);
-    if (res2_) (void)hipFree(res2_);
-    if (stream2_) (void)hipStreamDestroy(stream2_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    for (XLane &L : xl_) {
+        if (L.state) (void)hipFree(L.state);
+        if (L.frame) (void)hipFree(L.frame);
+        if (L.syn) (void)hipFree(L.syn);
+        if (L.res) (void)hipFree(L.res);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.join) (void)hipEventDestroy(L.join);
+    }
     for (auto &kv : obs_) (void)hipFree(kv.second.d_ett);
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
@@ -217,23 +219,26 @@ Session::~Session() {
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
-// Second lane of forward state (fields, memory variables, boundary frames, seismograms, residual) and its stream.
-void Session::ensure_lane2(bool with_frames) {
+// Extra lanes of forward state (fields, memory variables, boundary frames, seismograms, residual) and their streams.
+void Session::ensure_lanes(int n_lanes, bool with_frames) {
     const size_t n = cells_;
-    if (!stream2_) {
-        HIP_OK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    }
-    if (!lane2_state_) {
-        HIP_OK(hipMalloc((void **)&lane2_state_, 13 * n * sizeof(float)));
-        HIP_OK(hipMalloc((void **)&syn2_, 4 * data_len_ * sizeof(float)));
-        HIP_OK(hipMalloc((void **)&res2_, data_len_ * sizeof(float)));
-        device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
-    }
-    if (with_frames && !frame2_) {
-        const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
-        HIP_OK(hipMalloc((void **)&frame2_, fb));
-        device_bytes_ += (long long)fb;
+    for (int k = 1; k < n_lanes && k < kMaxLanes; k++) {
+        XLane &L = xl_[k];
+        if (!L.stream) {
+            HIP_OK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
+        }
+        if (!L.state) {
+            HIP_OK(hipMalloc((void **)&L.state, 13 * n * sizeof(float)));
+            HIP_OK(hipMalloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
+            HIP_OK(hipMalloc((void **)&L.res, data_len_ * sizeof(float)));
+            device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
+        }
+        if (with_frames && !L.frame) {
+            const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
+            HIP_OK(hipMalloc((void **)&L.frame, fb));
+            device_bytes_ += (long long)fb;
+        }
     }
 }
 
@@ -414,9 +419,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     }
     if (if_res)  // observed data of every shot of the call resident before the time loops start
         for (int is = 0; is < group_size; is++) (void)observed_ett(shot_ids[is], survey_.shots[shot_ids[is]].nrec, st);
-    const bool can_pair = (fuse_fwd == 0) && get_kernel_option("pair_fwd") != 0 && group_size >= 2;
+    int n_lanes = get_kernel_option("pair_fwd") ? get_kernel_option("fwd_lanes") : 1;  // concurrent forward passes
+    if (fuse_fwd != 0 || group_size < 2) n_lanes = 1;
+    if (n_lanes > group_size) n_lanes = group_size;
+    if (n_lanes > kMaxLanes) n_lanes = kMaxLanes;
+    const bool can_pair = n_lanes >= 2;
     const bool pair_bwd = can_pair && withAdj && get_kernel_option("pair_bwd") != 0;
-    if (can_pair) ensure_lane2(withAdj);
+    if (can_pair) ensure_lanes(n_lanes, withAdj);
     if (pair_bwd) {
         ensure_bwd_lane2(st);
         HIP_OK(hipMemsetAsync(bwd2_acc_.lam, 0, 5 * n * sizeof(float), st));
@@ -443,14 +452,14 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             c.line.x0 = sh.x_rec[0];
             c.line.n = c.nrec;
         }
-        c.state = lane ? lane2_state_ : state_;
+        c.state = lane ? xl_[lane].state : state_;
         float *b = c.state;
         c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
         c.fcur = c.fld;
         c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
-        c.frame = lane ? frame2_ : frame_;
-        c.syn = lane ? syn2_ : syn_;
-        c.res = lane ? res2_ : res_;
+        c.frame = lane ? xl_[lane].frame : frame_;
+        c.syn = lane ? xl_[lane].syn : syn_;
+        c.res = lane ? xl_[lane].res : res_;
         c.st = lane_st;
         return c;
     };
@@ -708,7 +717,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         // boundary frames, seismograms, residual are per lane; the backward pass has its own memory variables).
         // Working set = 5 (forward lane) + 15 (backward) + 5 (media) arrays of 8.8 MB: still inside the 256 MB
         // Infinity Cache, and each pass fills the kernel-boundary gaps and tails of the other.
-        ensure_lane2(true);
+        ensure_lanes(2, true);
         ensure_bwd_mem();
         HIP_OK(hipEventRecord(ev_[0], st));
         HIP_OK(hipStreamWaitEvent(stream2_, ev_[0], 0));
@@ -760,19 +769,19 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     }
 
     for (int is = 0; is < group_size && !pipelined;) {
-        const int np = (can_pair && is + 1 < group_size) ? 2 : 1;
-        ShotCtx ctx[2];
+        const int np = can_pair ? std::min(n_lanes, group_size - is) : 1;
+        ShotCtx ctx[kMaxLanes];
         ctx[0] = make_ctx(is, 0, st);
-        if (np == 2) ctx[1] = make_ctx(is + 1, 1, stream2_);
+        for (int k = 1; k < np; k++) ctx[k] = make_ctx(is + k, k, xl_[k].stream);
 
         // ---------------- forward time loop(s), libCUFD.cu:268-332 ----------------
         HIP_OK(hipEventRecord(ev_[0], st));
-        if (np == 2) HIP_OK(hipStreamWaitEvent(stream2_, ev_[0], 0));  // lane 2 starts after everything queued so far
+        for (int k = 1; k < np; k++) HIP_OK(hipStreamWaitEvent(xl_[k].stream, ev_[0], 0));  // extra lanes start after everything queued so far
         for (int k = 0; k < np; k++) forward_init(ctx[k]);
         if (fuse_fwd) {
             forward_fused(ctx[0]);
         } else {
-            bool inl[2];
+            bool inl[kMaxLanes];
             for (int k = 0; k < np; k++) inl[k] = forward_inline(ctx[k]);
             for (int it = 0; it <= nSteps - 2; it++)
                 for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
@@ -781,9 +790,9 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         if (if_res)
             for (int k = 0; k < np; k++) residual(ctx[k]);
-        if (np == 2) {  // join: the main stream continues when lane 2 is done
-            HIP_OK(hipEventRecord(ev_join_, stream2_));
-            HIP_OK(hipStreamWaitEvent(st, ev_join_, 0));
+        for (int k = 1; k < np; k++) {  // join: the main stream continues when the extra lanes are done
+            HIP_OK(hipEventRecord(xl_[k].join, xl_[k].stream));
+            HIP_OK(hipStreamWaitEvent(st, xl_[k].join, 0));
         }
         HIP_OK(hipEventRecord(ev_[1], st));
         fwd_steps_ += (long long)np * (nSteps - 1);
@@ -802,11 +811,10 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             }
         }
         if (withAdj) {
-            if (np == 2 && pair_bwd) {
-                backward(ctx, 2);
-            } else {
-                for (int k = 0; k < np; k++) backward(&ctx[k], 1);
-            }
+            int k = 0;
+            if (pair_bwd)
+                for (; k + 1 < np; k += 2) backward(&ctx[k], 2);
+            for (; k < np; k++) backward(&ctx[k], 1);
         }
         is += np;
     }

@@ -38,7 +38,7 @@ class Session {
   private:
     template <class T> T *dalloc(size_t n);
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
-    void ensure_lane2(bool with_frames);
+    void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_bwd_mem();
     void ensure_bwd_lane2(hipStream_t st);
 
@@ -65,9 +65,18 @@ class Session {
     long long device_bytes_ = 0;
 
     size_t cells_ = 0, data_len_ = 0;
-    float *lane2_state_ = nullptr, *frame2_ = nullptr, *syn2_ = nullptr, *res2_ = nullptr;  // second forward lane
-    hipStream_t stream2_ = nullptr;
-    hipEvent_t ev_join_ = nullptr, ev_fwd_[2] = {nullptr, nullptr}, ev_bwd_[2] = {nullptr, nullptr};
+    // extra forward lanes (lane 0 = state_/frame_/syn_/res_ on the call's stream): fields + memories, frames, seismograms,
+    // residual, stream, join event.  Lane 1 doubles as the second backward lane's stream.
+    static constexpr int kMaxLanes = 4;
+    struct XLane {
+        float *state = nullptr, *frame = nullptr, *syn = nullptr, *res = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t join = nullptr;
+    };
+    XLane xl_[kMaxLanes];
+    hipStream_t &stream2_ = xl_[1].stream;
+    hipEvent_t &ev_join_ = xl_[1].join;
+    hipEvent_t ev_fwd_[2] = {nullptr, nullptr}, ev_bwd_[2] = {nullptr, nullptr};
     PmlMem bwd_mem_{};  // backward-pass memory variables of the pipelined mode
     size_t stf_grad_len_ = 0;
     PmlMem bwd2_mem_{};  // second backward lane (pair_bwd)
