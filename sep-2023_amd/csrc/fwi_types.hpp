@@ -31,6 +31,7 @@ struct Grid {
     // optionally renumbered so that each XCD (blockIdx % 8) owns a contiguous band of tiles
     int gx, gy, bz, xcd_remap;
     int fiber;    // DAS fibre direction: 0 horizontal (exx), 1 vertical (ezz)
+    int rk_lazy;  // 1: adjoint kernels read 1/K only inside the layers
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
 };
 

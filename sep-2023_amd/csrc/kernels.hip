@@ -50,6 +50,7 @@ int g_opt_pair_bwd = 0;             // 1: backward passes of two shots run concu
 int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 never, 1 always, 2 only while two backward passes overlap
 int g_opt_early = 1;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
 int g_opt_rho_fly = 1;              // buoyancy averages rebuilt from the density: bit 0 forward velocity kernel (+3.6 %), bit 1 backward kernels (-1.2 %)
+int g_opt_rk_lazy = 1;              // adjoint kernels load 1/K only inside the C-PML layers (it is exactly 1 elsewhere)
 int g_opt_pipe_bwd = 0;             // 1: backward of shot k overlaps the forward of shot k+1 (session.cpp)
 int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
@@ -303,6 +304,22 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
 // rare C-PML branches, stores): a wave waits once for all of them, and the fused backward kernels can issue the
 // LOAD of their second update before the first update's stores (a store keeps later may-alias loads behind it).
 // ---------------------------------------------------------------------------------------------
+// 1/K of the four C-PML profiles at (z, x).  K is exactly 1 outside the layers (cpmlInit, utilities.cu:272-275,
+// 344-353: the damping profile is zero there; tests/test_host_logic.py checks it on the profiles), and a product with
+// 1.0f is exact, so the interior skips the four loads without changing a bit.
+__device__ __forceinline__ void load_rK(const Grid &g, const PmlCoef &pc, int z, int x, float &rKx, float &rKxh, float &rKz,
+                                        float &rKzh) {
+    rKx = rKxh = rKz = rKzh = 1.0f;
+    if (g.rk_lazy == 0 || x < g.nPml || x > g.nx - g.nPml - 1) {
+        rKx = pc.rK_x[x];
+        rKxh = pc.rK_xh[x];
+    }
+    if (g.rk_lazy == 0 || in_pml_z(g, z)) {
+        rKz = pc.rK_z[z];
+        rKzh = pc.rK_zh[z];
+    }
+}
+
 struct VelAdjIn {
     bool on;
     float szz_xm1, szz_0, szz_xp1, szz_xp2, szz_zm1, szz_zp1, szz_zp2;
@@ -325,7 +342,7 @@ __device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell 
     q.sxz_xm2 = f.sxz[i - 2]; q.sxz_xm1 = f.sxz[i - 1]; q.sxz_xp1 = f.sxz[i + 1];
     q.vx = f.vx[i]; q.vz = f.vz[i];
     q.lam = md.lam[i]; q.mu = md.mu[i]; q.amu = md.ave_mu[i];
-    q.rKx = pc.rK_x[x]; q.rKxh = pc.rK_xh[x]; q.rKz = pc.rK_z[z]; q.rKzh = pc.rK_zh[z];
+    load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
 __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
@@ -413,7 +430,7 @@ __device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell
     q.vx_xm2 = f.vx[i - 2]; q.vx_xm1 = f.vx[i - 1]; q.vx_xp1 = f.vx[i + 1];
     q.sxz = f.sxz[i]; q.sxx = f.sxx[i]; q.szz = f.szz[i];
     buoyancies(g, md, i, q.ba, q.bb);
-    q.rKx = pc.rK_x[x]; q.rKxh = pc.rK_xh[x]; q.rKz = pc.rK_z[z]; q.rKzh = pc.rK_zh[z];
+    load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
 __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
@@ -784,6 +801,7 @@ static inline Grid tiled(const Grid &g0, int rho_bit = -1) {
     g.gy = (g.nzc + g.bz - 1) / g.bz;
     g.xcd_remap = g_opt_xcd_remap;
     g.rho_fly = rho_bit < 0 ? 0 : (g_opt_rho_fly >> rho_bit) & 1;
+    g.rk_lazy = g_opt_rk_lazy;
     return g;
 }
 static inline dim3 field_grid(const Grid &g) {
@@ -807,6 +825,7 @@ int get_kernel_option(const char *name) {
     if (n == "fwd_lanes") return g_opt_fwd_lanes;
     if (n == "pipe_bwd") return g_opt_pipe_bwd;
     if (n == "pair_bwd") return g_opt_pair_bwd;
+    if (n == "rk_lazy") return g_opt_rk_lazy;
     if (n == "rho_fly") return g_opt_rho_fly;
     if (n == "early") return g_opt_early;
     if (n == "acc_nt") return g_opt_acc_nt;
@@ -826,6 +845,7 @@ int set_kernel_option(const char *name, int value) {
     if (n == "fwd_lanes" && value >= 1 && value <= 4) { g_opt_fwd_lanes = value; return 0; }
     if (n == "pipe_bwd") { g_opt_pipe_bwd = value ? 1 : 0; return 0; }
     if (n == "pair_bwd") { g_opt_pair_bwd = value ? 1 : 0; return 0; }
+    if (n == "rk_lazy") { g_opt_rk_lazy = value ? 1 : 0; return 0; }
     if (n == "rho_fly" && value >= 0 && value <= 3) { g_opt_rho_fly = value; return 0; }
     if (n == "early" && value >= 0 && value <= 3) { g_opt_early = value; return 0; }
     if (n == "acc_nt" && value >= 0 && value <= 2) { g_opt_acc_nt = value; return 0; }

@@ -188,3 +188,19 @@ def test_das_fiber_key_is_optional_and_validated(tmp_path):
     assert json.load(open(b))["das_fiber"] == "vertical"
     with pytest.raises(ValueError):
         ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 12, a, "s.json", str(tmp_path / "D"), das_fiber="diagonal")
+
+
+@pytest.mark.parametrize("N,nPml,dh,f0,dt", [(2064, 32, 10.0, 10.0, 1e-3), (1064, 32, 10.0, 10.0, 1e-3), (80, 10, 10.0, 25.0, 1e-3), (265, 32, 20.0, 10.0, 2e-3)])
+def test_cpml_profiles_are_trivial_outside_the_layers(N, nPml, dh, f0, dt):
+    """The kernels skip the a-terms and the 1/K loads outside `x < nPml or x > N-nPml-1`: K must be exactly 1 and a exactly 0
+    there, for the integer and the half-grid profiles (cpmlInit, utilities.cu:243-359)."""
+    from sepfwi import _native
+    L = _native.lib()
+    arrs = [np.zeros(N, np.float32) for _ in range(6)]
+    _native.check(L.sepfwi_cpml_profiles(*[a.ctypes.data for a in arrs], N, nPml, dh, f0, dt))
+    K, a, b, Kh, ah, bh = arrs
+    inside = np.arange(N)
+    layer = (inside < nPml) | (inside > N - nPml - 1)
+    for prof, one in ((K, 1.0), (Kh, 1.0), (a, 0.0), (ah, 0.0)):
+        assert np.all(prof[~layer] == one)
+    assert np.any(K[layer] != 1.0) and np.any(a[layer] != 0.0)
