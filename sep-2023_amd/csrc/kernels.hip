@@ -9,8 +9,11 @@
 //   k_stress<REV>    add_source(-) + el_stress(isFor=false) el_stress.cu:92-125 + to_bnd(szz,sxz,sxx)
 //   k_velocity_adj   el_velocity_adj.cu:57-102
 //   k_stress_adj     el_stress_adj.cu:53-97
-//   k_record         recording, recording_vx, recording_vz, recording_exx (utilities.cu:593-602,645-703)
-//   k_inject         res_injection_exx (utilities.cu:605-615)
+//   k_bwd_a          k_velocity<REV> + k_stress_adj of the previous step in one launch   } the default backward step:
+//   k_bwd_b          source_grad + k_stress<REV> + k_velocity_adj + line injection       } two launches
+//   k_bwd_velocity / k_bwd_stress   the other legal pairing (option bwd_fuse=1)
+//   k_record         recording, recording_vx, recording_vz, recording_exx / _ezz (utilities.cu:593-602,620-629,645-703)
+//   k_inject         res_injection_exx / _ezz (utilities.cu:605-615,632-641)
 //   k_residual       gpuMinus + cuda_cal_objective (utilities.cu:154-205)
 //   k_model_prep     host transpose x MEGA (libCUFD.cu:71-77) + velInit/aveMuInit/aveBycInit
 //                    (utilities.cu:109-152, Model.cu:66-87)
@@ -19,7 +22,8 @@
 //
 // Arrays are row-major, x fastest, pitch `g.pitch` (fwi_types.hpp).  A wave covers 64 consecutive
 // x of one row, so every global access of a wave is one 256-B line-aligned segment (plus the +-1/+-2
-// shifted re-reads that hit the same lines in the vector L1).
+// shifted re-reads that hit the same lines in the vector L1).  Every cell update reads all its operands before its
+// first store (one memory round trip per wave, DESIGN.md 3.1 "loads first").
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -35,7 +39,6 @@ using namespace dev;
 namespace {
 
 constexpr int BX = 64;              // threads along x  (one wave)
-constexpr int OCC8 = 8;             // waves per SIMD the register allocator must leave room for (SGPRs <= 80)
 constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
 
 int g_opt_bz = 1;                   // waves (rows) per block
