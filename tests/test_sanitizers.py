@@ -1,0 +1,23 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer run of the device-free host code of libsepfwi (JSON reader, parameter /
+survey parsers, C-PML profiles, source taper, shot split) on well-formed and randomly damaged documents.  GPU sanitizers
+are not available on the target pool; this is the CPU build the sanitizers can see."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_parsers_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "config_sanitize")
+    src = [os.path.join(ROOT, "tests", "native", "config_sanitize.cpp"), os.path.join(ROOT, "sep-2023_amd", "csrc", "config.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-o", exe] + src)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    for seed in (1, 2, 3):
+        out = subprocess.run([exe, str(seed), "3000"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.startswith("OK"), out.stdout + out.stderr
