@@ -79,6 +79,27 @@ struct LineRec {
     const float *res;            // backward: this step's residual column
 };
 
+// Device-side description of one shot of a BATCHED launch (grid.y = shot of the batch): the per-shot pointers and
+// scalars the reference passes as kernel arguments.  Per-step quantities (boundary-frame block, seismogram column,
+// residual column, source amplitude) are derived in the kernel from the step index, so all launches of a time loop
+// have the same argument list except `it`.
+struct ShotDev {
+    float *fields;        // vz, vx, szz, sxx, sxz (stride n)
+    float *mem;           // forward: 8 C-PML memory variables (stride n)
+    float *frame;         // boundary frames [nSteps][5][frame_len] or null
+    float *syn;           // seismograms [4][data_len], time-major
+    const float *stf;     // tapered source time function, nSteps floats
+    float *bmem;          // backward: 8 memory variables, 5 adjoint fields, 5 accumulators (stride n)
+    float *adj;
+    float *acc;
+    const float *res;     // axial-strain residual [it][rec]
+    float *stf_grad;      // nSteps floats
+    int z_src, x_src;
+    int lr_z, lr_x0, lr_n;  // horizontal line of channels (lr_n == 0: separate k_record / k_inject launches)
+    int comps, nrec;
+    float src_rxz;
+};
+
 // Receivers grouped by the tile (of the fused forward kernel) that owns their cell: CSR over tiles.
 struct RecTiles {
     const int *off;   // [ntiles+1]

@@ -54,6 +54,10 @@ int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 neve
 int g_opt_early = 1;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
 int g_opt_rho_fly = 1;              // buoyancy averages rebuilt from the density: bit 0 forward velocity kernel (+3.6 %), bit 1 backward kernels (-1.2 %)
 int g_opt_rk_lazy = 1;              // adjoint kernels load 1/K only inside the C-PML layers (it is exactly 1 elsewhere)
+int g_opt_batch = 2;                // the shots of a call advance in batched launches (grid.y = shot): 0 never (one stream per forward
+                                    // lane), 1 always, 2 when at least two backward passes fit the cache budget together
+int g_opt_batch_f = 0, g_opt_batch_b = 0;  // explicit forward / backward batch sizes (0: from batch_mb)
+int g_opt_batch_mb = 200;           // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
 int g_opt_pipe_bwd = 0;             // 1: backward of shot k overlaps the forward of shot k+1 (session.cpp)
 int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
 
@@ -613,6 +617,88 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Batched forms: blockIdx.y selects one shot of a batch (ShotDev table in device memory), blockIdx.x the tile as before.
+// One launch advances EVERY shot of the batch by a half step.  Small grids stop being launch-bound (the reference issues
+// 24 launches per shot and time step; the stream form 4; this one 4 / batch), and on the headline grid the three
+// concurrent forward passes become one launch whose blocks pack without stream scheduling.  Same bodies as above.
+// ---------------------------------------------------------------------------------------------
+template <bool SAVE>
+__global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
+                                                           const float *__restrict__ cz, size_t n, size_t data_len, int it,
+                                                           float src_scale) {
+    const ShotDev &s = shots[blockIdx.y];
+    const Fields f = fields_of(s.fields, n);
+    const PmlMem m = mem_of(s.mem, n);
+    const Media md = media_of(media, n);
+    const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
+    float *frame_t = SAVE ? s.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
+    const float amp = src_scale * s.stf[it] * g.dt;  // scale*stf[it]*dt in the session's order of operations
+    LineRec lr{};
+    if ((s.comps & 16) && it >= 1) {  // bit 16: line sampled here; column `it` = velocities at the start of step `it`
+        lr.z = s.lr_z;
+        lr.x0 = s.lr_x0;
+        lr.n = s.lr_n;
+        const size_t c0 = (size_t)it * (size_t)s.nrec;
+        lr.d_vx = (s.comps & 2) ? s.syn + data_len + c0 : nullptr;
+        lr.d_vz = (s.comps & 4) ? s.syn + 2 * data_len + c0 : nullptr;
+        lr.d_ett = (s.comps & 8) ? s.syn + 3 * data_len + c0 : nullptr;
+    }
+    stress_body<true, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, ImgAcc{}, lr);
+}
+__global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
+                                                             const float *__restrict__ cz, size_t n) {
+    const ShotDev &s = shots[blockIdx.y];
+    const Fields f = fields_of(s.fields, n);
+    const PmlMem m = mem_of(s.mem, n);
+    const Media md = media_of(media, n);
+    const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
+    velocity_body<true>(g, my_cell(g), f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, ImgAcc{});
+}
+template <bool EARLY>
+__global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
+                                                      const float *__restrict__ cz, size_t n, int it) {
+    const ShotDev &s = shots[blockIdx.y];
+    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    const PmlMem m = mem_of(s.bmem, n);
+    const Media md = media_of(media, n);
+    const ImgAcc acc = acc_of(s.acc, n);
+    const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
+    const float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
+    const Cell c = my_cell(g);
+    if constexpr (EARLY) {
+        const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
+        velocity_body<false, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        stress_adj_apply(q, g, c, adj, m, md, pc);
+    } else {
+        velocity_body<false, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        stress_adj_body(g, c, adj, m, md, pc);
+    }
+}
+template <bool EARLY>
+__global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
+                                                      const float *__restrict__ cz, size_t n, int it, float src_scale) {
+    const ShotDev &s = shots[blockIdx.y];
+    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    const PmlMem m = mem_of(s.bmem, n);
+    const Media md = media_of(media, n);
+    const ImgAcc acc = acc_of(s.acc, n);
+    const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
+    float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
+    const float amp = src_scale * s.stf[it] * g.dt;
+    const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
+    const Cell c = my_cell(g);
+    if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
+    if constexpr (EARLY) {
+        const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
+        stress_body<false, false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+        velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
+    } else {
+        stress_body<false, false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+        velocity_adj_body(g, c, adj, m, md, pc, lr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // receivers.  Seismograms are kept time-major on the device: d[comp][it][rec]  (coalesced for a
 // horizontal fibre); they are transposed to the reference's [rec][it] files only on export.
 // comps bit mask: 1 pressure, 2 vx, 4 vz, 8 ett.
@@ -828,6 +914,10 @@ int get_kernel_option(const char *name) {
     if (n == "fwd_lanes") return g_opt_fwd_lanes;
     if (n == "pipe_bwd") return g_opt_pipe_bwd;
     if (n == "pair_bwd") return g_opt_pair_bwd;
+    if (n == "batch") return g_opt_batch;
+    if (n == "batch_f") return g_opt_batch_f;
+    if (n == "batch_b") return g_opt_batch_b;
+    if (n == "batch_mb") return g_opt_batch_mb;
     if (n == "rk_lazy") return g_opt_rk_lazy;
     if (n == "rho_fly") return g_opt_rho_fly;
     if (n == "early") return g_opt_early;
@@ -848,6 +938,10 @@ int set_kernel_option(const char *name, int value) {
     if (n == "fwd_lanes" && value >= 1 && value <= 4) { g_opt_fwd_lanes = value; return 0; }
     if (n == "pipe_bwd") { g_opt_pipe_bwd = value ? 1 : 0; return 0; }
     if (n == "pair_bwd") { g_opt_pair_bwd = value ? 1 : 0; return 0; }
+    if (n == "batch" && value >= 0 && value <= 2) { g_opt_batch = value; return 0; }
+    if (n == "batch_f" && value >= 0 && value <= 64) { g_opt_batch_f = value; return 0; }
+    if (n == "batch_b" && value >= 0 && value <= 64) { g_opt_batch_b = value; return 0; }
+    if (n == "batch_mb" && value >= 1) { g_opt_batch_mb = value; return 0; }
     if (n == "rk_lazy") { g_opt_rk_lazy = value ? 1 : 0; return 0; }
     if (n == "rho_fly" && value >= 0 && value <= 3) { g_opt_rho_fly = value; return 0; }
     if (n == "early" && value >= 0 && value <= 3) { g_opt_early = value; return 0; }
@@ -948,6 +1042,41 @@ __global__ void k_add_inplace(float *__restrict__ a, const float *__restrict__ b
 }
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n) {
     hipLaunchKernelGGL(k_add_inplace, dim3(4096), dim3(256), 0, st, a, b, n);
+}
+
+// ---- batched launchers: grid = (tiles, shots of the batch)
+static inline dim3 batch_grid(const Grid &g, int nb) {
+    dim3 d = field_grid(g);
+    d.y = (unsigned)nb;
+    return d;
+}
+void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n,
+                             size_t data_len, int it, float src_scale, bool save) {
+    const Grid g = tiled(g0);
+    if (save)
+        hipLaunchKernelGGL(k_stress_fwd_batch<true>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
+    else
+        hipLaunchKernelGGL(k_stress_fwd_batch<false>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
+}
+void launch_velocity_fwd_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n) {
+    const Grid g = tiled(g0, 0);
+    hipLaunchKernelGGL(k_velocity_fwd_batch, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
+}
+void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it) {
+    const Grid g = tiled(g0, 1);
+    if (g_opt_early & 1)
+        hipLaunchKernelGGL(k_bwd_a_batch<true>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
+    else
+        hipLaunchKernelGGL(k_bwd_a_batch<false>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
+}
+void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it,
+                        float src_scale, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const Grid g = tiled(g0);
+    auto k = (g_opt_early & 2) ? k_bwd_b_batch<true> : k_bwd_b_batch<false>;
+    if (ev_start)
+        hipExtLaunchKernelGGL(k, batch_grid(g, nb), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);
+    else
+        hipLaunchKernelGGL(k, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it, src_scale);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

@@ -25,6 +25,13 @@ void launch_bwd_a(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, P
 void launch_bwd_b(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
                   int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool acc_nt = false);
+// batched forms (grid.y = shot of the batch; ShotDev table in device memory)
+void launch_stress_fwd_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n,
+                             size_t data_len, int it, float src_scale, bool save);
+void launch_velocity_fwd_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n);
+void launch_bwd_a_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it);
+void launch_bwd_b_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it,
+                        float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
 int get_kernel_option_bwd_fuse();
 int get_kernel_option(const char *name);

@@ -201,6 +201,15 @@ Session::~Session() {
         if (ev_fwd_[k]) (void)hipEventDestroy(ev_fwd_[k]);
         if (ev_bwd_[k]) (void)hipEventDestroy(ev_bwd_[k]);
     }
+    for (BLane &L : bl_) {
+        if (L.state) (void)hipFree(L.state);
+        if (L.bwd) (void)hipFree(L.bwd);
+        if (L.frame) (void)hipFree(L.frame);
+        if (L.syn) (void)hipFree(L.syn);
+        if (L.res) (void)hipFree(L.res);
+    }
+    if (d_shots_) (void)hipFree(d_shots_);
+    if (d_stf_) (void)hipFree(d_stf_);
     for (XLane &L : xl_) {
         if (L.state) (void)hipFree(L.state);
         if (L.frame) (void)hipFree(L.frame);
@@ -239,6 +248,44 @@ void Session::ensure_lanes(int n_lanes, bool with_frames) {
             HIP_OK(hipMalloc((void **)&L.frame, fb));
             device_bytes_ += (long long)fb;
         }
+    }
+}
+
+// Batched mode: n_fwd lanes of forward state, the first n_bwd of them with backward state too; shot table and source rows
+// for n_shots shots.
+void Session::ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots) {
+    const size_t n = cells_;
+    if ((int)bl_.size() < n_fwd) bl_.resize(n_fwd);
+    for (int k = 0; k < n_fwd; k++) {
+        BLane &L = bl_[k];
+        if (!L.state) {
+            HIP_OK(hipMalloc((void **)&L.state, 13 * n * sizeof(float)));
+            HIP_OK(hipMalloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
+            HIP_OK(hipMalloc((void **)&L.res, data_len_ * sizeof(float)));
+            device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
+        }
+        if (with_frames && !L.frame) {
+            const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
+            HIP_OK(hipMalloc((void **)&L.frame, fb));
+            device_bytes_ += (long long)fb;
+        }
+        if (k < n_bwd && !L.bwd) {
+            HIP_OK(hipMalloc((void **)&L.bwd, 18 * n * sizeof(float)));
+            device_bytes_ += (long long)(18 * n * sizeof(float));
+        }
+    }
+    if (n_shots > shots_cap_) {
+        if (d_shots_) (void)hipFree(d_shots_);
+        d_shots_ = nullptr;
+        HIP_OK(hipMalloc((void **)&d_shots_, (size_t)n_shots * sizeof(ShotDev)));
+        shots_cap_ = n_shots;
+    }
+    const size_t need = (size_t)n_shots * par_.nSteps;
+    if (need > d_stf_len_) {
+        if (d_stf_) (void)hipFree(d_stf_);
+        d_stf_ = nullptr;
+        HIP_OK(hipMalloc((void **)&d_stf_, need * sizeof(float)));
+        d_stf_len_ = need;
     }
 }
 
@@ -711,6 +758,142 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
 
     const bool scratch_any = withAdj && !par_.scratch_dir_name.empty();
     const bool pipelined = withAdj && fuse_fwd == 0 && get_kernel_option("pipe_bwd") != 0 && group_size >= 2 && !scratch_any;
+    // ---------------- batched mode: every launch advances a whole batch of shots (grid.y = shot) ----------------
+    // Batch sizes from the Infinity-Cache budget: a forward batch keeps 5 fields per shot + 5 media arrays resident, a
+    // backward batch 15 arrays per shot + 5 (2000x500: 7 and 2; a 101x201 notebook problem: all its shots at once).  Where
+    // not even two backward passes fit (2000x1000) the stream mode below is faster: its three forward passes overlap
+    // kernels of different kinds, and its kernels are long enough (13-32 us) not to be launch-bound.
+    const double arr_mb = (double)n * sizeof(float) / 1.0e6, budget = (double)get_kernel_option("batch_mb");
+    int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
+    const int batch_opt = get_kernel_option("batch");
+    const bool batched = !pipelined && fuse_fwd == 0 && fuse_bwd == 2 && group_size >= 1 && (batch_opt == 1 || (batch_opt == 2 && Bb >= 2));
+    if (batched) {
+        if (get_kernel_option("batch_f") > 0) Bf = get_kernel_option("batch_f");
+        if (get_kernel_option("batch_b") > 0) Bb = get_kernel_option("batch_b");
+        Bf = std::max(1, std::min(std::min(Bf, 32), group_size));
+        Bb = std::max(1, std::min(Bb, Bf));
+        if (!get_kernel_option("pair_fwd")) Bf = Bb = 1;
+        ensure_batch(Bf, withAdj ? Bb : 0, withAdj, group_size);
+        HIP_OK(hipMemcpyAsync(d_stf_, stf_rows.data(), (size_t)group_size * nSteps * sizeof(float), hipMemcpyHostToDevice, st));
+        const bool lf = get_kernel_option("line_fuse") != 0;
+        auto lane_ctx = [&](int is) {  // shot `is` of the call in its batch lane
+            ShotCtx c = make_ctx(is, 0, st);
+            const BLane &L = bl_[is % Bf];
+            c.state = L.state;
+            float *b = c.state;
+            c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
+            c.fcur = c.fld;
+            c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
+            c.frame = L.frame;
+            c.syn = L.syn;
+            c.res = L.res;
+            return c;
+        };
+        std::vector<ShotDev> tab(group_size);
+        for (int is = 0; is < group_size; is++) {
+            const ShotCtx c = lane_ctx(is);
+            const BLane &LB = bl_[(is % Bf) % Bb];  // backward lane of this shot inside its sub-batch
+            ShotDev &d = tab[is];
+            d.fields = c.state;
+            d.mem = c.state + 5 * n;
+            d.frame = c.frame;
+            d.syn = c.syn;
+            d.stf = d_stf_ + (size_t)is * nSteps;
+            d.bmem = withAdj ? LB.bwd : nullptr;
+            d.adj = withAdj ? LB.bwd + 8 * n : nullptr;
+            d.acc = withAdj ? LB.bwd + 13 * n : nullptr;
+            d.res = c.res;
+            d.stf_grad = withAdj ? stf_grad_ + (size_t)is * nSteps : nullptr;
+            d.z_src = c.sh->z_src;
+            d.x_src = c.sh->x_src;
+            d.lr_z = c.line.z;
+            d.lr_x0 = c.line.x0;
+            d.lr_n = lf ? c.line.n : 0;
+            d.comps = c.comps | ((lf && c.line.n > 0 && !(c.comps & 1)) ? 16 : 0);  // bit 16: sample the line inside k_stress
+            d.nrec = c.nrec;
+            d.src_rxz = (float)c.sh->src_rxz;
+        }
+        HIP_OK(hipMemcpyAsync(d_shots_, tab.data(), tab.size() * sizeof(ShotDev), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));  // `tab` and `stf_rows` are pageable host memory
+        if (withAdj)
+            for (int k = 0; k < Bb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd + 13 * n, 0, 5 * n * sizeof(float), st));
+
+        for (int is0 = 0; is0 < group_size; is0 += Bf) {
+            const int nb = std::min(Bf, group_size - is0);
+            std::vector<ShotCtx> cx;
+            for (int k = 0; k < nb; k++) cx.push_back(lane_ctx(is0 + k));
+            // ---- forward time loop, libCUFD.cu:268-332
+            HIP_OK(hipEventRecord(ev_[0], st));
+            for (int k = 0; k < nb; k++) forward_init(cx[k]);
+            for (int it = 0; it <= nSteps - 2; it++) {
+                launch_stress_fwd_batch(st, g, d_shots_ + is0, nb, md_, pc_, n, data_len_, it, src_scale, withAdj);
+                launch_velocity_fwd_batch(st, g, d_shots_ + is0, nb, md_, pc_, n);
+                launches_ += 2;
+                for (int k = 0; k < nb; k++)
+                    if (!(tab[is0 + k].comps & 16)) {  // general receivers: sample the new state into column it+1
+                        const ShotCtx &c = cx[k];
+                        const size_t col = (size_t)(it + 1) * c.nrec;
+                        launch_record(st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+                        launches_++;
+                    }
+            }
+            for (int k = 0; k < nb; k++)
+                if (tab[is0 + k].comps & 16) forward_last_column(cx[k]);
+            if (if_res)
+                for (int k = 0; k < nb; k++) residual(cx[k]);
+            HIP_OK(hipEventRecord(ev_[1], st));
+            fwd_steps_ += (long long)nb * (nSteps - 1);
+            HIP_OK(hipStreamSynchronize(st));
+            {
+                float ms = 0.f;
+                HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+                fwd_ms_ += ms;
+            }
+            for (int k = 0; k < nb; k++) {
+                if (!if_res) {
+                    export_gathers(cx[k]);
+                } else if (cx[k].scratch) {
+                    scratch_dumps(cx[k]);
+                }
+            }
+            // ---- backward time loops in sub-batches, libCUFD.cu:500-675
+            for (int kb = 0; withAdj && kb < nb; kb += Bb) {
+                const int nbb = std::min(Bb, nb - kb);
+                HIP_OK(hipEventRecord(ev_[2], st));
+                for (int k = 0; k < nbb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd, 0, 13 * n * sizeof(float), st));  // memories + adjoint fields
+                for (int it = nSteps - 2; it >= 0; it--) {
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0) {
+                        e0 = probe_ev_[2 * n_probe];
+                        e1 = probe_ev_[2 * n_probe + 1];
+                        n_probe++;
+                    }
+                    launch_bwd_a_batch(st, g, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
+                    launch_bwd_b_batch(st, g, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, src_scale, e0, e1);
+                    launches_ += 2;
+                    for (int k = 0; k < nbb; k++)
+                        if (tab[is0 + kb + k].lr_n == 0) {
+                            const ShotCtx &c = cx[kb + k];
+                            const Fields adj = Fields{bl_[k].bwd + 8 * n, bl_[k].bwd + 9 * n, bl_[k].bwd + 10 * n, bl_[k].bwd + 11 * n, bl_[k].bwd + 12 * n};
+                            launch_inject(st, adj, c.nrec, c.rec, c.res + (size_t)it * c.nrec, par_.fiber ? g.pitch : 0);
+                            launches_++;
+                        }
+                }
+                HIP_OK(hipEventRecord(ev_[3], st));
+                bwd_steps_ += (long long)nbb * (nSteps - 1);
+                HIP_OK(hipStreamSynchronize(st));
+                collect_probes();
+                float ms = 0.f;
+                HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
+                bwd_ms_ += ms;
+            }
+        }
+        if (withAdj)  // the batch lanes' accumulators -> the session's (zeroed above), summed in lane order
+            for (int k = 0; k < Bb; k++) {
+                launch_add_inplace(st, acc_.lam, bl_[k].bwd + 13 * n, 5 * n);
+                launches_++;
+            }
+    }
     if (pipelined) {
         // Software pipeline over the shots of the call: while the backward pass of shot k runs on the main stream,
         // the forward pass of shot k+1 runs on the second stream in the other lane (fields, memory variables,
@@ -768,7 +951,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         bwd_ms_ += ms * (124.0 / 184.0);
     }
 
-    for (int is = 0; is < group_size && !pipelined;) {
+    for (int is = 0; is < group_size && !pipelined && !batched;) {
         const int np = can_pair ? std::min(n_lanes, group_size - is) : 1;
         ShotCtx ctx[kMaxLanes];
         ctx[0] = make_ctx(is, 0, st);

@@ -39,6 +39,7 @@ class Session {
     template <class T> T *dalloc(size_t n);
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
     void ensure_lanes(int n_lanes, bool with_frames);
+    void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void ensure_bwd_mem();
     void ensure_bwd_lane2(hipStream_t st);
 
@@ -79,6 +80,16 @@ class Session {
     hipEvent_t ev_fwd_[2] = {nullptr, nullptr}, ev_bwd_[2] = {nullptr, nullptr};
     PmlMem bwd_mem_{};  // backward-pass memory variables of the pipelined mode
     size_t stf_grad_len_ = 0;
+    // batched mode: lanes of per-shot state (forward: fields + memories, frames, seismograms, residual; backward: memories,
+    // adjoint fields, accumulators) and the device table of the call's shots
+    struct BLane {
+        float *state = nullptr, *bwd = nullptr, *frame = nullptr, *syn = nullptr, *res = nullptr;
+    };
+    std::vector<BLane> bl_;
+    ShotDev *d_shots_ = nullptr;
+    int shots_cap_ = 0;
+    float *d_stf_ = nullptr;
+    size_t d_stf_len_ = 0;
     PmlMem bwd2_mem_{};  // second backward lane (pair_bwd)
     Fields bwd2_adj_{};
     ImgAcc bwd2_acc_{};
