@@ -221,7 +221,7 @@ def main():
                 "value": round(value, 4), "unit": "Gcell-updates/s", "n_gpus": world, "steps": K, "warmup": W,
                 "ms_per_step": round(el * 1e3 / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "configs[2] shape: %dx%d model (padded %dx%d), %d time steps, %d DAS channels, "
+                "config": {"workload": ("configs[2]" if args.mode == "fwdadj" else "configs[1]") + " shape: %dx%d model (padded %dx%d), %d time steps, %d DAS channels, "
                                        "%d shot(s) per GPU per step, %s" % (args.nx, args.nz, pb["nx_pad"], pb["nz_pad"], args.nsteps,
                                                                         pb["nrec"], spr, "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
                            "cell_updates_per_shot": updates_per_shot, "shots_per_gpu_per_step": spr, "parallelism": "shots x%d" % world},
