@@ -766,7 +766,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     const double arr_mb = (double)n * sizeof(float) / 1.0e6, budget = (double)get_kernel_option("batch_mb");
     int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
     const int batch_opt = get_kernel_option("batch");
-    const bool batched = !pipelined && fuse_fwd == 0 && fuse_bwd == 2 && group_size >= 1 && (batch_opt == 1 || (batch_opt == 2 && Bb >= 2));
+    const bool batched = !pipelined && fuse_fwd == 0 && fuse_bwd == 2 && group_size >= 1 && (batch_opt == 1 || (batch_opt == 2 && (withAdj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
     if (batched) {
         if (get_kernel_option("batch_f") > 0) Bf = get_kernel_option("batch_f");
         if (get_kernel_option("batch_b") > 0) Bb = get_kernel_option("batch_b");
