@@ -44,7 +44,8 @@ constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (r
 int g_opt_bz = 1;                   // waves (rows) per block
 int g_opt_xcd_remap = 1;            // 1: each XCD gets a contiguous band of tiles
 int g_opt_bwd_fuse = 2;             // backward step: 0 four kernels, 1 {vel,vel}/{stress,stress} pairs, 2 {vel,adj stress}/{stress,adj vel} pairs
-int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip)
+int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip),
+                                    // 3 the whole time loop as one persistent launch (fwd_persist.hip)
 int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
 int g_opt_march_waves = 1280;       // target number of waves of the z-marching forward kernel
 int g_opt_pair_fwd = 1;             // 1: forward passes of several shots run concurrently, one stream each
@@ -930,7 +931,7 @@ int set_kernel_option(const char *name, int value) {
     if (n == "bz" && value >= 1 && value <= 16) { g_opt_bz = value; return 0; }
     if (n == "xcd_remap") { g_opt_xcd_remap = value ? 1 : 0; return 0; }
     if (n == "bwd_fuse" && value >= 0 && value <= 2) { g_opt_bwd_fuse = value; return 0; }
-    if (n == "fwd_fuse" && value >= 0 && value <= 2) { g_opt_fwd_fuse = value; return 0; }
+    if (n == "fwd_fuse" && value >= 0 && value <= 3) { g_opt_fwd_fuse = value; return 0; }
     if (n == "line_fuse") { g_opt_line_fuse = value ? 1 : 0; return 0; }
     if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
     if (n == "march_waves" && value >= 1) { g_opt_march_waves = value; return 0; }

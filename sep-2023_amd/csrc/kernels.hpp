@@ -50,6 +50,13 @@ void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const
 void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
                                float *gDen);
 
+// persistent forward time loop (fwd_persist.hip): one launch per shot
+int persist_bands(const Grid &g, int n_cus);            // 0: grid not supported
+size_t persist_halo_floats(const Grid &g, int nb);      // per halo buffer
+bool launch_fwd_persist(hipStream_t st, const Grid &g, const ShotDev &shot, Media md, PmlCoef pc, size_t n, size_t data_len,
+                        float src_scale, int nsteps, int nb, bool save, float *haloV, float *haloS, int *flagV, int *flagS,
+                        int *abort_flag, int rho_fly);
+
 // run-time kernel options ("bz": rows per block 1..16, "xcd_remap": 0/1); returns 0 or -1
 int set_kernel_option(const char *name, int value);
 

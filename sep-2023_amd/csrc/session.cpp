@@ -208,6 +208,8 @@ Session::~Session() {
         if (L.syn) (void)hipFree(L.syn);
         if (L.res) (void)hipFree(L.res);
     }
+    if (p_halo_) (void)hipFree(p_halo_);
+    if (p_flags_) (void)hipFree(p_flags_);
     if (d_shots_) (void)hipFree(d_shots_);
     if (d_stf_) (void)hipFree(d_stf_);
     for (XLane &L : xl_) {
@@ -543,6 +545,61 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const size_t col = (size_t)(nSteps - 1) * c.nrec;
         launch_record(c.st, g, c.fcur, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
         launches_++;
+    };
+    // persistent forward time loop (fwd_persist.hip): ONE launch per shot, fields register-resident; false = not applicable
+    // (receivers not an inline-sampled line, grid too tall / wide, kernel not co-resident) -> the two-kernel form runs
+    bool stf_on_device = false;
+    auto forward_persist = [&](ShotCtx &c) -> bool {
+        if (!(c.nrec == 0 || (c.line.n > 0 && !(c.comps & 1) && get_kernel_option("line_fuse") != 0))) return false;
+        if (n_cus_ == 0) {
+            hipDeviceProp_t prop;
+            HIP_OK(hipGetDeviceProperties(&prop, gpu_id_));
+            n_cus_ = prop.multiProcessorCount;
+        }
+        const int nb = persist_bands(g, n_cus_);
+        if (nb == 0) return false;
+        const size_t hf = persist_halo_floats(g, nb);
+        if (!p_halo_ || p_nb_ != nb) {
+            if (p_halo_) (void)hipFree(p_halo_);
+            if (p_flags_) (void)hipFree(p_flags_);
+            p_halo_ = nullptr;
+            p_flags_ = nullptr;
+            HIP_OK(hipMalloc((void **)&p_halo_, 2 * hf * sizeof(float)));
+            HIP_OK(hipMalloc((void **)&p_flags_, (size_t)(2 * nb + 1) * 32 * sizeof(int)));
+            p_nb_ = nb;
+        }
+        if (!stf_on_device) {
+            ensure_batch(0, 0, false, group_size);
+            HIP_OK(hipMemcpy(d_stf_, stf_rows.data(), (size_t)group_size * nSteps * sizeof(float), hipMemcpyHostToDevice));
+            stf_on_device = true;
+        }
+        HIP_OK(hipMemsetAsync(p_halo_, 0, 2 * hf * sizeof(float), c.st));
+        HIP_OK(hipMemsetAsync(p_flags_, 0, (size_t)(2 * nb + 1) * 32 * sizeof(int), c.st));
+        ShotDev d{};
+        d.fields = c.state;
+        d.mem = c.state + 5 * n;
+        d.frame = withAdj ? c.frame : nullptr;
+        d.syn = c.syn;
+        d.stf = d_stf_ + (size_t)c.is * nSteps;
+        d.z_src = c.sh->z_src;
+        d.x_src = c.sh->x_src;
+        d.lr_z = c.line.z;
+        d.lr_x0 = c.line.x0;
+        d.lr_n = c.line.n;
+        d.comps = c.comps | (c.line.n > 0 ? 16 : 0);
+        d.nrec = c.nrec;
+        d.src_rxz = (float)c.sh->src_rxz;
+        int *flagV = p_flags_, *flagS = p_flags_ + nb * 32, *abortf = p_flags_ + 2 * nb * 32;
+        if (!launch_fwd_persist(c.st, g, d, md_, pc_, n, data_len_, src_scale, nSteps - 1, nb, withAdj, p_halo_, p_halo_ + hf, flagV,
+                                flagS, abortf, get_kernel_option("rho_fly") & 1))
+            return false;
+        launches_++;
+        if (c.line.n > 0) forward_last_column(c);
+        HIP_OK(hipStreamSynchronize(c.st));
+        int aborted = 0;
+        HIP_OK(hipMemcpy(&aborted, abortf, sizeof(int), hipMemcpyDeviceToHost));
+        if (aborted) throw HipError("persistent forward kernel aborted: a band waited too long for its neighbour");
+        return true;
     };
     // fused single-launch forward steps (lane 0 only): 1 = LDS-tiled (fwd_fused.hip), 2 = z-marching (fwd_march.hip)
     auto forward_fused = [&](ShotCtx &c) {
@@ -961,7 +1018,10 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         HIP_OK(hipEventRecord(ev_[0], st));
         for (int k = 1; k < np; k++) HIP_OK(hipStreamWaitEvent(xl_[k].stream, ev_[0], 0));  // extra lanes start after everything queued so far
         for (int k = 0; k < np; k++) forward_init(ctx[k]);
-        if (fuse_fwd) {
+        bool fwd_done = false;
+        if (fuse_fwd == 3) fwd_done = forward_persist(ctx[0]);
+        if (fwd_done) {
+        } else if (fuse_fwd == 1 || fuse_fwd == 2) {
             forward_fused(ctx[0]);
         } else {
             bool inl[kMaxLanes];

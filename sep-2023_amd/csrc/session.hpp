@@ -90,6 +90,10 @@ class Session {
     int shots_cap_ = 0;
     float *d_stf_ = nullptr;
     size_t d_stf_len_ = 0;
+    // persistent forward time loop (fwd_fuse=3): halo exchange buffers, step flags, abort flag
+    float *p_halo_ = nullptr;
+    int *p_flags_ = nullptr;
+    int p_nb_ = 0, n_cus_ = 0;
     PmlMem bwd2_mem_{};  // second backward lane (pair_bwd)
     Fields bwd2_adj_{};
     ImgAcc bwd2_acc_{};

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
-SOURCES = ["kernels.hip", "fwd_fused.hip", "fwd_march.hip", "session.cpp", "config.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "fwd_fused.hip", "fwd_march.hip", "fwd_persist.hip", "session.cpp", "config.cpp", "capi.cpp"]
 HEADERS = ["kernels.hpp", "device_common.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
