@@ -150,7 +150,7 @@ __global__ __launch_bounds__(PT) void k_fwd_persist(Grid g, PersistArgs a) {
         __syncthreads();
         {
             float *frame_t = a.save ? s.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-            const float amp = a.src_scale * s.stf[it] * g.dt;
+            const float amp = __fmul_rn(__fmul_rn(a.src_scale, s.stf[it]), g.dt);  // rounded like the host's float product
             const bool rec = (s.comps & 16) && it >= 1;  // line receivers: column `it` = velocities at the start of step `it`
             const size_t c0 = (size_t)it * (size_t)s.nrec;
             float *d_vx = (rec && (s.comps & 2)) ? s.syn + a.data_len + c0 : nullptr;

@@ -633,7 +633,8 @@ __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
     float *frame_t = SAVE ? s.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-    const float amp = src_scale * s.stf[it] * g.dt;  // scale*stf[it]*dt in the session's order of operations
+    // scale*stf[it]*dt rounded like the host's float product of the stream form (no contraction into the later add)
+    const float amp = __fmul_rn(__fmul_rn(src_scale, s.stf[it]), g.dt);
     LineRec lr{};
     if ((s.comps & 16) && it >= 1) {  // bit 16: line sampled here; column `it` = velocities at the start of step `it`
         lr.z = s.lr_z;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
     const ImgAcc acc = acc_of(s.acc, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
     float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
-    const float amp = src_scale * s.stf[it] * g.dt;
+    const float amp = __fmul_rn(__fmul_rn(src_scale, s.stf[it]), g.dt);
     const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
     const Cell c = my_cell(g);
     if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
