@@ -84,6 +84,14 @@ int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float 
 /* Frees every cached session (device memory, cached observed data) of this process. */
 void sepfwi_release_all(void);
 
+/*
+ * Observed axial-strain data of one shot from memory instead of Shot_ett{id}.bin (the reference re-reads
+ * four files per shot on every call, Src/libCUFD.cu:216-223).  `ett` is [nrec][nSteps] float32 like the file, host or
+ * device pointer; the session keeps a time-major copy in HBM and uses it for every later misfit / gradient call of that
+ * shot until sepfwi_invalidate_observed() or sepfwi_release_all().  No file is needed for shots set this way.
+ */
+int sepfwi_set_observed(const char *para_fname, int gpu_id, int shot_id, const float *ett, int nrec, int nSteps);
+
 /* Drops cached observed data (e.g. after the Shot_*.bin files were rewritten by another tool). */
 void sepfwi_invalidate_observed(void);
 

@@ -81,6 +81,13 @@ void sepfwi_release_all(void) {
     try { release_all_sessions(); } catch (...) {}
 }
 
+int sepfwi_set_observed(const char *para_fname, int gpu_id, int shot_id, const float *ett, int nrec, int nSteps) {
+    return guarded([&] {
+        if (!para_fname) throw std::invalid_argument("para_fname is NULL");
+        get_session(para_fname, gpu_id).set_observed(shot_id, ett, nrec, nSteps);
+    });
+}
+
 void sepfwi_invalidate_observed(void) {
     try { invalidate_observed_all(); } catch (...) {}
 }

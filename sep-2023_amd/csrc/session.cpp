@@ -329,8 +329,46 @@ void Session::drop_observed() {
 }
 
 // Observed axial-strain gather of one shot, time-major in HBM; (re)loaded when the file changed.
+void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) {
+    std::lock_guard<std::mutex> lock(mu_);
+    HIP_OK(hipSetDevice(gpu_id_));
+    if (shot_id < 0 || shot_id >= (int)survey_.shots.size() || !survey_.shots[shot_id].present)
+        throw std::invalid_argument("set_observed: unknown shot id " + std::to_string(shot_id));
+    if (!ett || nrec != survey_.shots[shot_id].nrec || nSteps != par_.nSteps)
+        throw std::invalid_argument("set_observed: data must be [nrec][nSteps] of the survey / parameter file");
+    const size_t want = (size_t)nrec * (size_t)nSteps * sizeof(float);
+    ObsEntry e;
+    auto it = obs_.find(shot_id);
+    if (it != obs_.end()) {
+        e = it->second;
+        if (e.bytes != want) {
+            (void)hipFree(e.d_ett);
+            device_bytes_ -= (long long)e.bytes;
+            e.d_ett = nullptr;
+        }
+    }
+    if (nrec > 0 && !e.d_ett) {
+        HIP_OK(hipMalloc((void **)&e.d_ett, want));
+        device_bytes_ += (long long)want;
+    }
+    e.bytes = want;
+    e.from_memory = true;
+    if (nrec > 0) {
+        hipStream_t st = own_stream_;
+        HIP_OK(hipMemcpyAsync(xpose_, ett, want, hipMemcpyDefault, st));
+        launch_transpose(st, xpose_, e.d_ett, nrec, nSteps);  // [rec][it] -> [it][rec]
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    obs_[shot_id] = e;
+}
+
 const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
     if (nrec <= 0) return nullptr;  // nothing to compare against
+    {
+        auto im = obs_.find(shot_id);
+        if (im != obs_.end() && im->second.from_memory && im->second.bytes == (size_t)nrec * (size_t)par_.nSteps * sizeof(float))
+            return im->second.d_ett;  // handed over through sepfwi_set_observed
+    }
     const std::string fn = shot_file(par_, 3, shot_id);
     struct stat sb;
     if (stat(fn.c_str(), &sb) != 0) throw IoError("cannot read observed data '" + fn + "'");  // utilities.cu:12-16
@@ -360,6 +398,7 @@ const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
         device_bytes_ += (long long)want;
     }
     e.bytes = want;
+    e.from_memory = false;
     e.size = (long long)sb.st_size;
     e.mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec;
     HIP_OK(hipMemcpyAsync(xpose_, h_io_, want, hipMemcpyHostToDevice, st));

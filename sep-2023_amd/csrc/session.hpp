@@ -33,6 +33,8 @@ class Session {
              hipStream_t ext_stream, bool async);
     void stats(sepfwi_stats *out) const;
     void drop_observed();
+    // observed axial strain of one shot from memory ([nrec][nSteps] like the files; host or device pointer)
+    void set_observed(int shot_id, const float *ett, int nrec, int nSteps);
     const Params &params() const { return par_; }
 
   private:
@@ -47,6 +49,7 @@ class Session {
         float *d_ett = nullptr;  // [nSteps][nrec]
         size_t bytes = 0;
         long long size = 0, mtime_ns = 0;
+        bool from_memory = false;  // handed over through sepfwi_set_observed: no file behind it
     };
 
     std::string para_fname_;

@@ -70,8 +70,9 @@ def lib():
     L.sepfwi_shot_split.argtypes = [C.c_int, C.c_int, ip]
     L.sepfwi_get_stats.argtypes = [C.c_char_p, C.c_int, C.POINTER(Stats)]
     L.sepfwi_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.sepfwi_set_observed.argtypes = [C.c_char_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
     for f in ("sepfwi_cufd", "sepfwi_cufd_stream", "sepfwi_cpml_profiles", "sepfwi_stf_taper", "sepfwi_shot_split",
-              "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_version", "sepfwi_device_count"):
+              "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_set_observed", "sepfwi_version", "sepfwi_device_count"):
         getattr(L, f).restype = C.c_int
     L.sepfwi_release_all.restype = None
     L.sepfwi_invalidate_observed.restype = None
@@ -81,7 +82,7 @@ def lib():
 
 EXPORTS = ["sepfwi_last_error", "sepfwi_version", "sepfwi_device_count", "sepfwi_cufd", "sepfwi_cufd_stream",
            "sepfwi_release_all", "sepfwi_invalidate_observed", "sepfwi_cpml_profiles", "sepfwi_stf_taper",
-           "sepfwi_shot_split", "sepfwi_get_stats", "sepfwi_set_option"]
+           "sepfwi_shot_split", "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_set_observed"]
 
 
 class SepFwiError(RuntimeError):

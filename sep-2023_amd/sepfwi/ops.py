@@ -137,6 +137,16 @@ class _FwiOps:
         return None
 
     # -- extras --------------------------------------------------------------------------------
+    def set_observed(self, para_fname, shot_id, ett, gpu_id=0):
+        """Observed axial-strain gather of one shot from a tensor ((nrec, nSteps) float32, CPU or HIP) instead of
+        Shot_ett{id}.bin: cached in HBM by the session of (para_fname, gpu_id) until release() / invalidation."""
+        ett = _f32c(ett, "ett")
+        if ett.dim() != 2:
+            raise ValueError("ett must be (nrec, nSteps)")
+        dev = self.device_override if self.device_override is not None else int(gpu_id)
+        _native.check(_native.lib().sepfwi_set_observed(str(para_fname).encode(), dev, int(shot_id), C.c_void_p(ett.data_ptr()),
+                                                        int(ett.shape[0]), int(ett.shape[1])))
+
     def stats(self, para_fname, gpu_id=0):
         st = _native.Stats()
         _native.check(_native.lib().sepfwi_get_stats(str(para_fname).encode(), int(gpu_id), C.byref(st)))
