@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Debug aid for tests/test_gpu_fuzz.py: rebuilds the random problem of one seed (line-receiver cases), prints GPU-vs-oracle and
+GPU-vs-GPU (stream / batched / unfused kernels) deviations of misfit, gradients and observed gathers and where they sit.
+usage: python scripts/fuzz_debug.py <seed>      (needs a GPU)"""
 import json, os, sys, tempfile
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
