@@ -130,9 +130,9 @@ int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 
 /*
  * Kernel-variant selection for A/B measurements and parity tests of every variant.  Names and
- * defaults (documented next to the g_opt_* variables of csrc/kernels.hip): bz 1, xcd_remap 1, bwd_fuse 2, fwd_fuse 0
+ * defaults (documented next to the g_opt_* variables of csrc/kernels.hip): bz 2, xcd_remap 1, bwd_fuse 2, fwd_fuse 0
  * (1 LDS-tiled, 2 z-marching, 3 persistent time loop), line_fuse 1, pair_fwd 1, fwd_lanes 3, pair_bwd 0, acc_nt 2,
- * pipe_bwd 0, early 1, rho_fly 1, rk_lazy 1, batch 2 (0 streams, 1 batched launches, 2 by grid size), batch_f 0,
+ * pipe_bwd 0, early 0, rho_fly 1, rk_lazy 1, batch 2 (0 streams, 1 batched launches, 2 by grid size), batch_f 0,
  * batch_b 0, batch_mb 200, probe 0, march_waves 1280.  Process-wide; results are identical (to the parity tolerances) for every setting.  Returns
  * SEPFWI_EINVAL for unknown names or values.
  */

@@ -41,7 +41,7 @@ namespace {
 constexpr int BX = 64;              // threads along x  (one wave)
 constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
 
-int g_opt_bz = 1;                   // waves (rows) per block
+int g_opt_bz = 2;                   // waves (rows) per block (re-tuned after -ffp-contract=off: 2 rows, no early loads)
 int g_opt_xcd_remap = 1;            // 1: each XCD gets a contiguous band of tiles
 int g_opt_bwd_fuse = 2;             // backward step: 0 four kernels, 1 {vel,vel}/{stress,stress} pairs, 2 {vel,adj stress}/{stress,adj vel} pairs
 int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip),
@@ -52,7 +52,7 @@ int g_opt_pair_fwd = 1;             // 1: forward passes of several shots run co
 int g_opt_fwd_lanes = 3;            // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
 int g_opt_pair_bwd = 0;             // 1: backward passes of two shots run concurrently (slower at 2000x1000: the pair does not fit the Infinity Cache)
 int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 never, 1 always, 2 only while two backward passes overlap
-int g_opt_early = 1;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
+int g_opt_early = 0;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
 int g_opt_rho_fly = 1;              // buoyancy averages rebuilt from the density: bit 0 forward velocity kernel (+3.6 %), bit 1 backward kernels (-1.2 %)
 int g_opt_rk_lazy = 1;              // adjoint kernels load 1/K only inside the C-PML layers (it is exactly 1 elsewhere)
 int g_opt_batch = 2;                // the shots of a call advance in batched launches (grid.y = shot): 0 never (one stream per forward
