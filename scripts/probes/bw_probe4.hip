@@ -74,10 +74,15 @@ __global__ __launch_bounds__(64) void v34(Arr a, unsigned nb) {
     for (int w = 5; w < 8; w++) { float4 v = ((float4 *)a.p[w])[i]; v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; ((float4 *)a.p[w])[i] = v; }
 }
 
-int main() {
+#include <cstdlib>
+int main(int argc, char **argv) {
     const size_t n = (size_t)ROWS * P;
     Arr a;
-    for (auto &p : a.p) { CK(hipMalloc((void **)&p, n * 4)); CK(hipMemset(p, 0, n * 4)); }
+    const bool random_data = argc > 1;   // any argument: arrays start from random floats instead of zeros (is the fabric data-dependent?)
+    std::vector<float> init(n);
+    for (size_t i = 0; i < n; i++) init[i] = random_data ? (float)rand() / RAND_MAX - 0.5f : 0.0f;
+    for (auto &p : a.p) { CK(hipMalloc((void **)&p, n * 4)); CK(hipMemcpy(p, init.data(), n * 4, hipMemcpyHostToDevice)); }
+    printf("arrays start from %s\n", random_data ? "random floats" : "zeros");
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 300;
     const unsigned nb1 = (unsigned)(n / 64), nb4 = (unsigned)(n / 256);
