@@ -84,7 +84,8 @@ def cpu_baseline(nz, nx, seconds=15.0):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build()
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    host_cores = os.cpu_count() or 1
+    cores = max(1, min(host_cores, 32))
     ndamp = 32
     vp = np.full((nx, nz), 3000.0)
     vs = vp / 1.732
@@ -107,7 +108,21 @@ def cpu_baseline(nz, nx, seconds=15.0):
     val = cores * cells * nt / el / 1e9
     return {"value": round(val, 5), "unit": "Gcell-updates/s", "cores": cores, "kind": "port",
             "sample": "float64 C restatement of elasticSolver.py (velocity+stress = 1 cell-update), %dx%d grid + %d sponge, "
-                      "%d steps, %d shots in parallel (one per core), forward only, %.1f s" % (nx, nz, ndamp, nt, cores, el)}
+                      "%d steps, %d shots in parallel (one per core; os.cpu_count() = %d, capped at 32), forward only, %.1f s"
+                      % (nx, nz, ndamp, nt, cores, host_cores, el)}
+
+
+def launcher_cmd(n_gpus, argv, port=None):
+    """`python bench.py --gpus N` without torchrun: the command line of the N-rank job this process turns itself into
+    (one rank per GPU over RCCL, rendezvous on 127.0.0.1) -- the same line the driver uses for N > 1."""
+    import socket
+    if port is None:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -122,17 +137,34 @@ def main():
     ap.add_argument("--mode", default="fwdadj", choices=["fwdadj", "fwd"])
     ap.add_argument("--shots-per-step", type=int, default=3,
                     help="shots each GPU processes per step (3: the forward passes of the three overlap on three streams)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box; use with --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: nothing has touched the GPU yet, so become the launcher of N ranks (child
+        # process; its exit code is ours) instead of silently measuring one GPU
+        import subprocess
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(launcher_cmd(args.gpus, sys.argv[1:]), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as td
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.share_gpu:      # rehearsal of the N-rank path on a one-GPU box: every rank drives device 0, gloo reduces on the host
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE under torchrun"
+        if args.backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     dev = torch.device("cuda", local)
@@ -188,7 +220,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             td.all_reduce(t, op=td.ReduceOp.MAX)
             el = float(t.item())
 

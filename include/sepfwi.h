@@ -129,14 +129,26 @@ typedef struct sepfwi_stats {
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 
 /*
- * Kernel-variant selection for A/B measurements and parity tests of every variant.  Names and
- * defaults (documented next to the g_opt_* variables of csrc/kernels.hip): bz 2, xcd_remap 1, bwd_fuse 2, fwd_fuse 0
- * (1 LDS-tiled, 2 z-marching, 3 persistent time loop), line_fuse 1, pair_fwd 1, fwd_lanes 3, pair_bwd 0, acc_nt 2,
- * pipe_bwd 0, early 0, rho_fly 1, rk_lazy 1, batch 2 (0 streams, 1 batched launches, 2 by grid size), batch_f 0,
- * batch_b 0, batch_mb 200, probe 0, march_waves 1280.  Process-wide; results are identical (to the parity tolerances) for every setting.  Returns
- * SEPFWI_EINVAL for unknown names or values.
+ * Kernel / scheduling options for A/B measurements and for the parity tests of every selectable structure.
+ * Names and defaults (struct KernelOptions, csrc/kernels.hpp): bz 2, xcd_remap 1, bwd_fuse 2 (0: the reference's four
+ * kernels per backward step), line_fuse 1, pair_fwd 1, fwd_lanes 3, early 0, rho_fly 1, amu_fly 0, rk_lazy 1, batch 2
+ * (0 streams, 1 batched launches, 2 by grid size), batch_f 0, batch_b 0, batch_mb 200, batch_order 1, pipe_bwd 0, probe 0.
+ * sepfwi_set_option edits the process-wide defaults under a lock; every sepfwi_cufd* call takes ONE snapshot of them when
+ * it starts, so a call never sees a half-changed block and concurrent calls on other GPUs are unaffected.  Results are
+ * identical (to the parity tolerances) for every setting.  Returns SEPFWI_EINVAL for unknown names or values;
+ * sepfwi_get_option returns the current default or -1.
  */
 int sepfwi_set_option(const char *name, int value);
+int sepfwi_get_option(const char *name);
+
+/*
+ * Test hook: wavefield `which` (0..4: vz, vx, szz, sxx, sxz; 5..9: their adjoint twins) of forward lane `lane` as the last
+ * sepfwi_cufd* call on (para_fname, gpu_id) left it, dense (nz - nPad, nx) row-major float32, host or device pointer.
+ * After a gradient call the forward fields are the reverse-time RECONSTRUCTION run back to time step 0, i.e. they must
+ * have returned to the zero initial state up to float32 round-off: the size-independent parity
+ * property checked at the full 2000 x 1000 x 4000 size, where the CPU oracle cannot go.
+ */
+int sepfwi_debug_field(const char *para_fname, int gpu_id, int lane, int which, float *out);
 
 #ifdef __cplusplus
 }

@@ -64,8 +64,8 @@ int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float 
         if (!Lambda || !Mu || !Den || !stf) throw std::invalid_argument("Lambda, Mu, Den and stf must not be NULL");
         if (group_size < 0 || (group_size > 0 && !shot_ids)) throw std::invalid_argument("bad shot list");
         if (calc_id == 1 && (!grad_Lambda || !grad_Mu || !grad_Den)) throw std::invalid_argument("gradient outputs must not be NULL for calc_id 1");
-        Session &s = get_session(para_fname, gpu_id);
-        s.run(misfit, grad_Lambda, grad_Mu, grad_Den, grad_stf, Lambda, Mu, Den, stf, calc_id, group_size, shot_ids,
+        std::shared_ptr<Session> s = get_session(para_fname, gpu_id);
+        s->run(misfit, grad_Lambda, grad_Mu, grad_Den, grad_stf, Lambda, Mu, Den, stf, calc_id, group_size, shot_ids,
               (hipStream_t)hip_stream, async != 0);
     });
 }
@@ -84,7 +84,7 @@ void sepfwi_release_all(void) {
 int sepfwi_set_observed(const char *para_fname, int gpu_id, int shot_id, const float *ett, int nrec, int nSteps) {
     return guarded([&] {
         if (!para_fname) throw std::invalid_argument("para_fname is NULL");
-        get_session(para_fname, gpu_id).set_observed(shot_id, ett, nrec, nSteps);
+        get_session(para_fname, gpu_id)->set_observed(shot_id, ett, nrec, nSteps);
     });
 }
 
@@ -118,11 +118,22 @@ int sepfwi_shot_split(int group_size, int ngpu, int *starts) {
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out) {
     return guarded([&] {
         if (!para_fname || !out) throw std::invalid_argument("bad arguments");
-        Session *s = find_session(para_fname, gpu_id);
+        std::shared_ptr<Session> s = find_session(para_fname, gpu_id);
         if (!s) throw std::invalid_argument("no session for this parameter file / gpu");
         s->stats(out);
     });
 }
+
+int sepfwi_debug_field(const char *para_fname, int gpu_id, int lane, int which, float *out) {
+    return guarded([&] {
+        if (!para_fname || !out) throw std::invalid_argument("bad arguments");
+        std::shared_ptr<Session> s = find_session(para_fname, gpu_id);
+        if (!s) throw std::invalid_argument("no session for this parameter file / gpu");
+        s->copy_field(lane, which, out);
+    });
+}
+
+int sepfwi_get_option(const char *name) { return get_kernel_option(name); }
 
 int sepfwi_set_option(const char *name, int value) {
     if (set_kernel_option(name, value) == 0) return SEPFWI_OK;

@@ -1,6 +1,7 @@
 // config.cpp -- host-side setup math: JSON -> Params/Survey, C-PML profiles, source taper, shot split.
 #include "config.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <fstream>
 #include <stdexcept>
@@ -59,9 +60,12 @@ Survey parse_survey(const std::string &text, int nPml) {
     Survey s;
     s.nShots = j.at("nShots").as_int("nShots");
     for (const auto &kv : j.obj) {
-        if (kv.first.compare(0, 4, "shot") != 0) continue;
-        const int id = std::atoi(kv.first.c_str() + 4);
-        if (id < 0) continue;
+        // "shot" followed by digits only ("shots_meta" or "shot-1" are not shots), id inside the declared range
+        if (kv.first.size() < 5 || kv.first.size() > 12 || kv.first.compare(0, 4, "shot") != 0) continue;
+        if (kv.first.find_first_not_of("0123456789", 4) != std::string::npos) continue;
+        const long id_l = std::atol(kv.first.c_str() + 4);
+        if (id_l >= (long)std::max(s.nShots, 0)) continue;  // the reference reads shot0 .. shot{nShots-1} only (Src_Rec.cu:74-77)
+        const int id = (int)id_l;
         if ((int)s.shots.size() <= id) s.shots.resize(id + 1);
         const JsonValue &js = kv.second;
         Shot sh;

@@ -33,6 +33,8 @@ struct Grid {
     int fiber;    // DAS fibre direction: 0 horizontal (exx), 1 vertical (ezz)
     int rk_lazy;  // 1: adjoint kernels read 1/K only inside the layers
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
+    int amu_fly;  // 1: the 4-point harmonic mean of mu recomputed from mu in the stress-type kernels
+    int nb, shot_fastest;  // batched launches: shots per grid and the order of (tile, shot) in the block index
 };
 
 // Five wavefields (or their adjoint twins), each nzc*pitch floats.
@@ -98,34 +100,6 @@ struct ShotDev {
     int lr_z, lr_x0, lr_n;  // horizontal line of channels (lr_n == 0: separate k_record / k_inject launches)
     int comps, nrec;
     float src_rxz;
-};
-
-// Receivers grouped by the tile (of the fused forward kernel) that owns their cell: CSR over tiles.
-struct RecTiles {
-    const int *off;   // [ntiles+1]
-    const int *cell;  // z*pitch + x
-    const int *rec;   // receiver index (column of the seismogram)
-};
-
-// Arguments of the fused forward step (fwd_fused.hip).  Arrays come as bundles "base + k*n":
-//   fo/fn : vz, vx, szz, sxx, sxz             (old / new wavefield)
-//   mo/mn : psi(dvz_dz), psi(dvz_dx), psi(dvx_dz), psi(dvx_dx)   (old / new stress-side C-PML memory)
-//   mv    : psi(dszz_dz), psi(dsxz_dx), psi(dsxz_dz), psi(dsxx_dx)   (velocity-side, in place)
-//   media : lam, mu, ave_mu, byc_a, byc_b ;   cz/cx: a, b, 1/K, a_half, b_half, 1/K_half  (6 x nzc / 6 x nx)
-struct FwdFusedArgs {
-    const float *fo;
-    float *fn;
-    const float *mo;
-    float *mn;
-    float *mv;
-    const float *media, *cz, *cx;
-    float *frame_t;
-    const int *rt_off, *rt_cell, *rt_rec;
-    float *d_pr, *d_vx, *d_vz, *d_ett;
-    unsigned n;
-    int z_src, x_src;
-    float src_amp;
-    int comps;
 };
 
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step

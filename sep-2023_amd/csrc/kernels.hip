@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <mutex>
 #include <string>
 
 #include "device_common.hpp"
@@ -41,41 +42,41 @@ namespace {
 constexpr int BX = 64;              // threads along x  (one wave)
 constexpr int MAXT = 1024;          // block = 64 x bz threads, bz in {1..16} (run-time option "bz")
 
-int g_opt_bz = 2;                   // waves (rows) per block (re-tuned after -ffp-contract=off: 2 rows, no early loads)
-int g_opt_xcd_remap = 1;            // 1: each XCD gets a contiguous band of tiles
-int g_opt_bwd_fuse = 2;             // backward step: 0 four kernels, 1 {vel,vel}/{stress,stress} pairs, 2 {vel,adj stress}/{stress,adj vel} pairs
-int g_opt_fwd_fuse = 0;             // forward step: 0 two kernels, 1 LDS-tiled fused (fwd_fused.hip), 2 z-marching fused (fwd_march.hip),
-                                    // 3 the whole time loop as one persistent launch (fwd_persist.hip)
-int g_opt_line_fuse = 1;            // 1: line receivers are sampled / injected inside the field kernels
-int g_opt_march_waves = 1280;       // target number of waves of the z-marching forward kernel
-int g_opt_pair_fwd = 1;             // 1: forward passes of several shots run concurrently, one stream each
-int g_opt_fwd_lanes = 3;            // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
-int g_opt_pair_bwd = 0;             // 1: backward passes of two shots run concurrently (slower at 2000x1000: the pair does not fit the Infinity Cache)
-int g_opt_acc_nt = 2;               // imaging accumulators non-temporal: 0 never, 1 always, 2 only while two backward passes overlap
-int g_opt_early = 0;                // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
-int g_opt_rho_fly = 1;              // buoyancy averages rebuilt from the density: bit 0 forward velocity kernel (+3.6 %), bit 1 backward kernels (-1.2 %)
-int g_opt_rk_lazy = 1;              // adjoint kernels load 1/K only inside the C-PML layers (it is exactly 1 elsewhere)
-int g_opt_batch = 2;                // the shots of a call advance in batched launches (grid.y = shot): 0 never (one stream per forward
-                                    // lane), 1 always, 2 when at least two backward passes fit the cache budget together
-int g_opt_batch_f = 0, g_opt_batch_b = 0;  // explicit forward / backward batch sizes (0: from batch_mb)
-int g_opt_batch_mb = 200;           // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
-int g_opt_pipe_bwd = 0;             // 1: backward of shot k overlaps the forward of shot k+1 (session.cpp)
-int g_opt_probe = 0;                // >0: time every probe-th k_bwd_stress launch with HIP events (bench.py roofline)
-
 struct Cell {
     int z, x;
     size_t i;  // z*pitch + x
 };
 
-__device__ __forceinline__ Cell my_cell(const Grid &g) {
+// Tile (and, in batched launches, shot) of this block.  Blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an
+// L2); with xcd_remap the logical order gives each XCD a contiguous run of logical indices, so z-halo rows are re-read
+// from the SAME L2 instead of once per XCD.  Batched launches (g.nb shots in one grid) order the pairs either shot-major
+// (all tiles of shot 0, then shot 1, ...) or, shot_fastest, tile-major: the nb shots of one tile are dispatched back to
+// back on one XCD, so the media coefficients of the tile (the same for every shot) are fetched from the fabric once
+// and hit that XCD's L2 for the other shots.
+__device__ __forceinline__ Cell my_cell(const Grid &g, int *shot = nullptr) {
     Cell c;
-    // tile id: blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an L2); with xcd_remap the
-    // logical tile order gives each XCD a contiguous band of rows so that z-halo rows are re-read from
-    // the SAME L2 instead of being fetched once per XCD.
     int t = blockIdx.x;
+    const int ntile = g.gx * g.gy;
+    const int nb = shot ? g.nb : 1;
     if (g.xcd_remap) {
-        const int per = (g.gx * g.gy + 7) >> 3;
+        const int per = (ntile * nb + 7) >> 3;
         t = (t & 7) * per + (t >> 3);
+    }
+    if (shot) {
+        int sh;
+        if (g.shot_fastest) {
+            const int q = t / nb;
+            sh = t - q * nb;
+            t = q;
+        } else {
+            sh = t / ntile;
+            t -= sh * ntile;
+            if (sh >= nb) {  // surplus block of the remapped numbering
+                sh = nb - 1;
+                t = ntile;
+            }
+        }
+        *shot = sh;
     }
     const int ty = t / g.gx, tx = t - ty * g.gx;
     c.x = tx * BX + (threadIdx.x & (BX - 1));
@@ -86,27 +87,26 @@ __device__ __forceinline__ Cell my_cell(const Grid &g) {
     return c;
 }
 
+// 4-point harmonic mean of mu at the staggered corner (z+1/2, x+1/2): aveMuInit, utilities.cu:124-137.  amu_fly: rebuilt
+// from mu (three neighbour taps that hit the cache) instead of streaming a second array; single precision with the
+// hardware reciprocal (<= 1 ulp each), i.e. within 4e-7 of the stored double-precision value -- the forward and the
+// reverse-time kernels evaluate the same expression, so reconstruction still cancels exactly.  A zero mu gives
+// 1/0 = inf -> 4/inf = 0, the reference's fluid rule.  Valid on [2, n-3]^2 (every cell the kernels update).
+__device__ __forceinline__ float ave_mu_at(const Grid &g, const Media &md, size_t i, float mu0) {
+    if (g.amu_fly) {
+        const float s = (__builtin_amdgcn_rcpf(mu0) + __builtin_amdgcn_rcpf(md.mu[i + g.pitch])) +
+                        (__builtin_amdgcn_rcpf(md.mu[i + 1]) + __builtin_amdgcn_rcpf(md.mu[i + g.pitch + 1]));
+        return 4.0f * __builtin_amdgcn_rcpf(s);
+    }
+    return md.ave_mu[i];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // stress update
 // ---------------------------------------------------------------------------------------------
-// Accumulator update.  NT: non-temporal accesses keep the imaging accumulators out of the 256 MB Infinity Cache
-// (scripts/probes/bw_probe3.hip) so that the fields of two concurrently running backward passes stay resident.
-template <bool NT>
-__device__ __forceinline__ float acc_load(const float *p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    return *p;
-}
-template <bool NT>
-__device__ __forceinline__ void acc_store(float *p, float v) {
-    if constexpr (NT)
-        __builtin_nontemporal_store(v, p);
-    else
-        *p = v;
-}
-
-template <bool FWD, bool SAVE, bool NT = false>
+template <bool FWD, bool SAVE>
 __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
@@ -137,7 +137,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
         float dvx_dx = dminus(f.vx[i - 2], vxm1, vx0, f.vx[i + 1], g.rdx);
         float dvx_dz = dplus(f.vx[i - P], vx0, f.vx[i + P], f.vx[i + 2 * P], g.rdz);
         float dvz_dx = dplus(f.vz[i - 1], vz0, f.vz[i + 1], f.vz[i + 2], g.rdx);
-        const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
+        const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
         const float szz0 = f.szz[i], sxx0 = f.sxx[i], sxz0 = f.sxz[i];
         if (lr.n && z == lr.z) {
             // line receivers: seismogram column `it` = velocities at the START of step `it`, which this kernel
@@ -194,17 +194,17 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             const float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
             const float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
             const float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
-            const float lam = md.lam[i], mu = md.mu[i], amu = md.ave_mu[i];
+            const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
             const float za = adj.szz[i], xa = adj.sxx[i], sa = adj.sxz[i];
-            const float g_lam = acc_load<NT>(acc.lam + i), g_mu = acc_load<NT>(acc.mu + i), g_xz = acc_load<NT>(acc.xz + i);
+            const float g_lam = acc.lam[i], g_mu = acc.mu[i], g_xz = acc.xz[i];
             const float l2m = lam + 2.0f * mu;
             szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
             sxx -= (lam * dvz_dz + l2m * dvx_dx) * g.dt;
             sxz -= amu * (dvx_dz + dvz_dx) * g.dt;
             // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
-            acc_store<NT>(acc.lam + i, g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt);
-            acc_store<NT>(acc.mu + i, g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt);
-            acc_store<NT>(acc.xz + i, g_xz + -sa * (dvx_dz + dvz_dx) * g.dt);
+            acc.lam[i] = g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt;
+            acc.mu[i] = g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt;
+            acc.xz[i] = g_xz + -sa * (dvx_dz + dvz_dx) * g.dt;
         }
         if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
             const int L = g.frame_len;
@@ -237,7 +237,7 @@ __device__ __forceinline__ void buoyancies(const Grid &g, const Media &md, size_
     }
 }
 
-template <bool FWD, bool NT = false>
+template <bool FWD>
 __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
                                               float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
@@ -285,14 +285,14 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             const float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
             const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
             const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
-            const float g_a = acc_load<NT>(acc.a + i), g_b = acc_load<NT>(acc.b + i), avz = adj.vz[i], avx = adj.vx[i];
+            const float g_a = acc.a[i], g_b = acc.b[i], avz = adj.vz[i], avx = adj.vx[i];
             float ba, bb;
             buoyancies(g, md, i, ba, bb);
             vz = f.vz[i] - (dszz_dz + dsxz_dx) * ba * g.dt;
             vx = f.vx[i] - (dsxz_dz + dsxx_dx) * bb * g.dt;
             // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
-            acc_store<NT>(acc.a + i, g_a + -avz * (dszz_dz + dsxz_dx) * g.dt);
-            acc_store<NT>(acc.b + i, g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt);
+            acc.a[i] = g_a + -avz * (dszz_dz + dsxz_dx) * g.dt;
+            acc.b[i] = g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt;
         }
         if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
             const int L = g.frame_len;
@@ -349,7 +349,7 @@ __device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell 
     q.sxz_zm2 = f.sxz[i - 2 * P]; q.sxz_zm1 = f.sxz[i - P]; q.sxz_0 = f.sxz[i]; q.sxz_zp1 = f.sxz[i + P];
     q.sxz_xm2 = f.sxz[i - 2]; q.sxz_xm1 = f.sxz[i - 1]; q.sxz_xp1 = f.sxz[i + 1];
     q.vx = f.vx[i]; q.vz = f.vz[i];
-    q.lam = md.lam[i]; q.mu = md.mu[i]; q.amu = md.ave_mu[i];
+    q.lam = md.lam[i]; q.mu = md.mu[i]; q.amu = ave_mu_at(g, md, i, q.mu);
     load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
@@ -517,32 +517,9 @@ __global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, Fields f, PmlMem m,
 }
 
 // ---------------------------------------------------------------------------------------------
-// ... and the backward step fused ACROSS its two independent chains (option "bwd_fuse" = 1):
-//   k_bwd_velocity = reverse-time velocity (+ source_grad, rho imaging, frame restore) and adjoint velocity
-//   k_bwd_stress   = reverse-time stress (+ source removal, lambda/mu imaging, frame restore) and adjoint stress
-// Both halves of a kernel only READ the stress-type (resp. velocity-type) arrays through their stencils and
-// read-modify-write their own cell of the velocity-type (resp. stress-type) arrays, so there is no
-// inter-thread hazard and no halo recomputation.  Order inside a thread keeps the reference semantics:
-// the imaging condition sees the adjoint field of the START of the step (libCUFD.cu:553-631: imaging
-// kernels run before the adjoint kernels), and the residual injection still happens between the two
-// kernels (k_inject).  4 field launches -> 2; 240 -> 200 algorithmic bytes per cell.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MAXT) void k_bwd_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
-                                                       const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
-                                                       float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
-    const Cell c = my_cell(g);
-    velocity_body<false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
-    velocity_adj_body(g, c, adj, m, md, pc, lr);
-}
-__global__ __launch_bounds__(MAXT) void k_bwd_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
-                                                     int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
-    const Cell c = my_cell(g);
-    stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
-    stress_adj_body(g, c, adj, m, md, pc);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward step, second pairing (option "bwd_fuse" = 2, default): the adjoint kernels need the OPPOSITE
+// Backward step fused ACROSS its two independent chains (option "bwd_fuse" = 2, default; 0 = the reference's four
+// kernels).  Reverse-time reconstruction and adjoint propagation only meet in the imaging condition, which reads the
+// adjoint field of the START of the step.  The adjoint kernels need the OPPOSITE
 // coefficient set of the reverse-time kernels of the same field type (adjoint stress uses the buoyancies,
 // adjoint velocity uses lambda/mu/ave_mu: el_stress_adj.cu:63-96, el_velocity_adj.cu:69-93).  Pairing
 //   k_bwd_a = reverse-time VELOCITY (+ rho imaging, frame restore)  +  adjoint STRESS of the PREVIOUS step
@@ -576,7 +553,7 @@ __device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int
                    cx, cx + nx,  cx + 2 * nx,  cx + 3 * nx,  cx + 4 * nx,  cx + 5 * nx};
 }
 
-template <bool NT, bool EARLY>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *__restrict__ frame_t) {
     const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
     const PmlMem m = mem_of(b.mem, b.n);
@@ -586,14 +563,14 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
     const Cell c = my_cell(g);
     if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-        velocity_body<false, NT>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false, NT>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
-template <bool NT, bool EARLY>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__restrict__ frame_t, int zx_src /* z<<16 | x */,
                                                 float src_amp, float src_rxz, float *__restrict__ stf_grad_it,
                                                 int lr_zx /* z<<16 | x0 */, int lr_n, const float *__restrict__ lr_res) {
@@ -609,16 +586,16 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
     if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
     if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-        stress_body<false, false, NT>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false, NT>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
         velocity_adj_body(g, c, adj, m, md, pc, lr);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Batched forms: blockIdx.y selects one shot of a batch (ShotDev table in device memory), blockIdx.x the tile as before.
+// Batched forms: the block index encodes (tile, shot of the batch) -- my_cell(); per-shot pointers in a ShotDev table in device memory.
 // One launch advances EVERY shot of the batch by a half step.  Small grids stop being launch-bound (the reference issues
 // 24 launches per shot and time step; the stream form 4; this one 4 / batch), and on the headline grid the three
 // concurrent forward passes become one launch whose blocks pack without stream scheduling.  Same bodies as above.
@@ -627,7 +604,9 @@ template <bool SAVE>
 __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                            const float *__restrict__ cz, size_t n, size_t data_len, int it,
                                                            float src_scale) {
-    const ShotDev &s = shots[blockIdx.y];
+    int ish;
+    const Cell c = my_cell(g, &ish);
+    const ShotDev &s = shots[ish];
     const Fields f = fields_of(s.fields, n);
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
@@ -645,41 +624,46 @@ __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev
         lr.d_vz = (s.comps & 4) ? s.syn + 2 * data_len + c0 : nullptr;
         lr.d_ett = (s.comps & 8) ? s.syn + 3 * data_len + c0 : nullptr;
     }
-    stress_body<true, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, ImgAcc{}, lr);
+    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, ImgAcc{}, lr);
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                              const float *__restrict__ cz, size_t n) {
-    const ShotDev &s = shots[blockIdx.y];
+    int ish;
+    const Cell c = my_cell(g, &ish);
+    const ShotDev &s = shots[ish];
     const Fields f = fields_of(s.fields, n);
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
-    velocity_body<true>(g, my_cell(g), f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, ImgAcc{});
+    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, ImgAcc{});
 }
 template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                       const float *__restrict__ cz, size_t n, int it) {
-    const ShotDev &s = shots[blockIdx.y];
+    int ish;
+    const Cell c = my_cell(g, &ish);
+    const ShotDev &s = shots[ish];
     const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(media, n);
     const ImgAcc acc = acc_of(s.acc, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
     const float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
-    const Cell c = my_cell(g);
     if constexpr (EARLY) {
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-        velocity_body<false, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
 template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                       const float *__restrict__ cz, size_t n, int it, float src_scale) {
-    const ShotDev &s = shots[blockIdx.y];
+    int ish;
+    const Cell c = my_cell(g, &ish);
+    const ShotDev &s = shots[ish];
     const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(media, n);
@@ -688,14 +672,13 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
     float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
     const float amp = __fmul_rn(__fmul_rn(src_scale, s.stf[it]), g.dt);
     const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
-    const Cell c = my_cell(g);
     if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
     if constexpr (EARLY) {
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-        stress_body<false, false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
         velocity_adj_body(g, c, adj, m, md, pc, lr);
     }
 }
@@ -883,16 +866,67 @@ __global__ void k_finalize_gradients(Grid g, Media md, ImgAcc acc, float *__rest
 }
 
 // =============================================================================================
-// launchers
+// options + launchers
 // =============================================================================================
-static inline Grid tiled(const Grid &g0, int rho_bit = -1) {
+// Process-wide DEFAULTS of the kernel options (sepfwi_set_option).  Nothing on the launch path reads them: every
+// Session::run takes one snapshot (kernel_options()) and hands it to the launchers, so sessions running on different
+// host threads (one per GPU) never see a half-updated block.
+static std::mutex g_opt_mu;
+static KernelOptions g_opt;
+
+KernelOptions kernel_options() {
+    std::lock_guard<std::mutex> lock(g_opt_mu);
+    return g_opt;
+}
+
+namespace {
+struct OptField {
+    const char *name;
+    int KernelOptions::*field;
+    int lo, hi;
+};
+const OptField kOptFields[] = {
+    {"bz", &KernelOptions::bz, 1, 16},           {"xcd_remap", &KernelOptions::xcd_remap, 0, 1},
+    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 2}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
+    {"pair_fwd", &KernelOptions::pair_fwd, 0, 1}, {"fwd_lanes", &KernelOptions::fwd_lanes, 1, 4},
+    {"early", &KernelOptions::early, 0, 3},       {"rho_fly", &KernelOptions::rho_fly, 0, 3},
+    {"amu_fly", &KernelOptions::amu_fly, 0, 3},   {"rk_lazy", &KernelOptions::rk_lazy, 0, 1},
+    {"batch", &KernelOptions::batch, 0, 2},       {"batch_f", &KernelOptions::batch_f, 0, 64},
+    {"batch_b", &KernelOptions::batch_b, 0, 64},  {"batch_mb", &KernelOptions::batch_mb, 1, 1 << 20},
+    {"batch_order", &KernelOptions::batch_order, 0, 1},
+    {"pipe_bwd", &KernelOptions::pipe_bwd, 0, 1}, {"probe", &KernelOptions::probe, 0, 1 << 30},
+};
+}  // namespace
+
+int get_kernel_option(const char *name) {
+    const std::string n(name ? name : "");
+    std::lock_guard<std::mutex> lock(g_opt_mu);
+    for (const OptField &f : kOptFields)
+        if (n == f.name) return g_opt.*(f.field);
+    return -1;
+}
+
+int set_kernel_option(const char *name, int value) {
+    const std::string n(name ? name : "");
+    std::lock_guard<std::mutex> lock(g_opt_mu);
+    for (const OptField &f : kOptFields)
+        if (n == f.name) {
+            if (value < f.lo || value > f.hi || (n == "bwd_fuse" && value == 1)) return -1;
+            g_opt.*(f.field) = value;
+            return 0;
+        }
+    return -1;
+}
+
+static inline Grid tiled(const Grid &g0, const KernelOptions &o, int fly_bit = -1) {
     Grid g = g0;
-    g.bz = g_opt_bz;
+    g.bz = o.bz;
     g.gx = (g.nx + BX - 1) / BX;
     g.gy = (g.nzc + g.bz - 1) / g.bz;
-    g.xcd_remap = g_opt_xcd_remap;
-    g.rho_fly = rho_bit < 0 ? 0 : (g_opt_rho_fly >> rho_bit) & 1;
-    g.rk_lazy = g_opt_rk_lazy;
+    g.xcd_remap = o.xcd_remap;
+    g.rho_fly = fly_bit < 0 ? 0 : (o.rho_fly >> fly_bit) & 1;
+    g.amu_fly = fly_bit < 0 ? 0 : (o.amu_fly >> fly_bit) & 1;
+    g.rk_lazy = o.rk_lazy;
     return g;
 }
 static inline dim3 field_grid(const Grid &g) {
@@ -901,59 +935,9 @@ static inline dim3 field_grid(const Grid &g) {
 }
 #define BLOCK dim3(BX *g.bz)
 
-int get_kernel_option_bwd_fuse() { return g_opt_bwd_fuse; }
-
-int get_kernel_option(const char *name) {
-    const std::string n(name ? name : "");
-    if (n == "bz") return g_opt_bz;
-    if (n == "xcd_remap") return g_opt_xcd_remap;
-    if (n == "bwd_fuse") return g_opt_bwd_fuse;
-    if (n == "fwd_fuse") return g_opt_fwd_fuse;
-    if (n == "line_fuse") return g_opt_line_fuse;
-    if (n == "probe") return g_opt_probe;
-    if (n == "march_waves") return g_opt_march_waves;
-    if (n == "pair_fwd") return g_opt_pair_fwd;
-    if (n == "fwd_lanes") return g_opt_fwd_lanes;
-    if (n == "pipe_bwd") return g_opt_pipe_bwd;
-    if (n == "pair_bwd") return g_opt_pair_bwd;
-    if (n == "batch") return g_opt_batch;
-    if (n == "batch_f") return g_opt_batch_f;
-    if (n == "batch_b") return g_opt_batch_b;
-    if (n == "batch_mb") return g_opt_batch_mb;
-    if (n == "rk_lazy") return g_opt_rk_lazy;
-    if (n == "rho_fly") return g_opt_rho_fly;
-    if (n == "early") return g_opt_early;
-    if (n == "acc_nt") return g_opt_acc_nt;
-    return -1;
-}
-
-int set_kernel_option(const char *name, int value) {
-    const std::string n(name ? name : "");
-    if (n == "bz" && value >= 1 && value <= 16) { g_opt_bz = value; return 0; }
-    if (n == "xcd_remap") { g_opt_xcd_remap = value ? 1 : 0; return 0; }
-    if (n == "bwd_fuse" && value >= 0 && value <= 2) { g_opt_bwd_fuse = value; return 0; }
-    if (n == "fwd_fuse" && value >= 0 && value <= 3) { g_opt_fwd_fuse = value; return 0; }
-    if (n == "line_fuse") { g_opt_line_fuse = value ? 1 : 0; return 0; }
-    if (n == "probe" && value >= 0) { g_opt_probe = value; return 0; }
-    if (n == "march_waves" && value >= 1) { g_opt_march_waves = value; return 0; }
-    if (n == "pair_fwd") { g_opt_pair_fwd = value ? 1 : 0; return 0; }
-    if (n == "fwd_lanes" && value >= 1 && value <= 4) { g_opt_fwd_lanes = value; return 0; }
-    if (n == "pipe_bwd") { g_opt_pipe_bwd = value ? 1 : 0; return 0; }
-    if (n == "pair_bwd") { g_opt_pair_bwd = value ? 1 : 0; return 0; }
-    if (n == "batch" && value >= 0 && value <= 2) { g_opt_batch = value; return 0; }
-    if (n == "batch_f" && value >= 0 && value <= 64) { g_opt_batch_f = value; return 0; }
-    if (n == "batch_b" && value >= 0 && value <= 64) { g_opt_batch_b = value; return 0; }
-    if (n == "batch_mb" && value >= 1) { g_opt_batch_mb = value; return 0; }
-    if (n == "rk_lazy") { g_opt_rk_lazy = value ? 1 : 0; return 0; }
-    if (n == "rho_fly" && value >= 0 && value <= 3) { g_opt_rho_fly = value; return 0; }
-    if (n == "early" && value >= 0 && value <= 3) { g_opt_early = value; return 0; }
-    if (n == "acc_nt" && value >= 0 && value <= 2) { g_opt_acc_nt = value; return 0; }
-    return -1;
-}
-
-void launch_stress_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
-                       int z_src, int x_src, float src_amp, LineRec lr) {
-    const Grid g = tiled(g0);
+void launch_stress_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
+                       float *frame_t, int z_src, int x_src, float src_amp, LineRec lr) {
+    const Grid g = tiled(g0, o, 0);
     Fields none{};
     ImgAcc na{};
     if (frame_t)
@@ -964,73 +948,54 @@ void launch_stress_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media
                            x_src, src_amp, none, na, lr);
 }
 
-void launch_velocity_fwd(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc) {
-    const Grid g = tiled(g0, 0);
+void launch_velocity_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc) {
+    const Grid g = tiled(g0, o, 0);
     Fields none{};
     ImgAcc na{};
     hipLaunchKernelGGL((k_velocity<true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, (const float *)nullptr,
                        -1, -1, 0.0f, (float *)nullptr, none, na);
 }
 
-void launch_velocity_rev(hipStream_t st, const Grid &g0, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
-                         int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
-    const Grid g = tiled(g0, 1);
+void launch_velocity_rev(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, Media md, PmlCoef pc,
+                         const float *frame_t, int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0, o, 1);
     PmlMem nm{};
     hipLaunchKernelGGL((k_velocity<false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src, x_src,
                        src_rxz, stf_grad_it, adj, acc);
 }
 
-void launch_stress_rev(hipStream_t st, const Grid &g0, Fields f, Media md, PmlCoef pc, float *frame_t, int z_src,
-                       int x_src, float src_amp, Fields adj, ImgAcc acc) {
-    const Grid g = tiled(g0);
+void launch_stress_rev(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, Media md, PmlCoef pc, float *frame_t,
+                       int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0, o, 1);
     PmlMem nm{};
     hipLaunchKernelGGL((k_stress<false, false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src,
                        x_src, src_amp, adj, acc, LineRec{});
 }
 
-void launch_velocity_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Media md, PmlCoef pc) {
-    const Grid g = tiled(g0);
+void launch_velocity_adj(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields adj, PmlMem m, Media md, PmlCoef pc) {
+    const Grid g = tiled(g0, o, 1);
     hipLaunchKernelGGL(k_velocity_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
-void launch_stress_adj(hipStream_t st, const Grid &g0, Fields adj, PmlMem m, Media md, PmlCoef pc) {
-    const Grid g = tiled(g0, 1);
+void launch_stress_adj(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields adj, PmlMem m, Media md, PmlCoef pc) {
+    const Grid g = tiled(g0, o, 1);
     hipLaunchKernelGGL(k_stress_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
-void launch_bwd_velocity(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
-                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr) {
-    const Grid g = tiled(g0, 1);
-    hipLaunchKernelGGL(k_bwd_velocity, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it,
-                       adj, acc, lr);
-}
-
-void launch_bwd_stress(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
-                       int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const Grid g = tiled(g0, 1);
-    if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
-        hipExtLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, f, m, md, pc, frame_t, z_src,
-                              x_src, src_amp, adj, acc);
-    else
-        hipLaunchKernelGGL(k_bwd_stress, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc);
-}
-
-void launch_bwd_a(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
-                  ImgAcc acc, bool acc_nt) {
-    const Grid g = tiled(g0, 1);
+void launch_bwd_a(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
+                  const float *frame_t, Fields adj, ImgAcc acc) {
+    const Grid g = tiled(g0, o, 1);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    const bool early = (g_opt_early & 1) != 0;
-    auto k = acc_nt ? (early ? k_bwd_a<true, true> : k_bwd_a<true, false>) : (early ? k_bwd_a<false, true> : k_bwd_a<false, false>);
+    auto k = (o.early & 1) ? k_bwd_a<true> : k_bwd_a<false>;
     hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
 
-void launch_bwd_b(hipStream_t st, const Grid &g0, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
-                  int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
-                  hipEvent_t ev_start, hipEvent_t ev_stop, bool acc_nt) {
-    const Grid g = tiled(g0);
+void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
+                  int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
+                  hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const Grid g = tiled(g0, o, 1);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    const bool early = (g_opt_early & 2) != 0;
-    auto k = acc_nt ? (early ? k_bwd_b<true, true> : k_bwd_b<true, false>) : (early ? k_bwd_b<false, true> : k_bwd_b<false, false>);
+    auto k = (o.early & 2) ? k_bwd_b<true> : k_bwd_b<false>;
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
         hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
                               src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
@@ -1046,39 +1011,46 @@ void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n) {
     hipLaunchKernelGGL(k_add_inplace, dim3(4096), dim3(256), 0, st, a, b, n);
 }
 
-// ---- batched launchers: grid = (tiles, shots of the batch)
-static inline dim3 batch_grid(const Grid &g, int nb) {
-    dim3 d = field_grid(g);
-    d.y = (unsigned)nb;
-    return d;
+// ---- batched launchers: one grid over (tile, shot of the batch); the order of the two is Grid::nb / batch_order
+static inline Grid tiled_batch(const Grid &g0, const KernelOptions &o, int fly_bit, int nb) {
+    Grid g = tiled(g0, o, fly_bit);
+    g.nb = nb;
+    g.shot_fastest = o.batch_order;
+    return g;
 }
-void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n,
-                             size_t data_len, int it, float src_scale, bool save) {
-    const Grid g = tiled(g0);
+static inline dim3 batch_grid(const Grid &g) {
+    const int nblk = g.gx * g.gy * g.nb;
+    return dim3(g.xcd_remap ? ((nblk + 7) / 8) * 8 : nblk);
+}
+void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
+                             PmlCoef pc, size_t n, size_t data_len, int it, float src_scale, bool save) {
+    const Grid g = tiled_batch(g0, o, 0, nb);
     if (save)
-        hipLaunchKernelGGL(k_stress_fwd_batch<true>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
+        hipLaunchKernelGGL(k_stress_fwd_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
     else
-        hipLaunchKernelGGL(k_stress_fwd_batch<false>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
+        hipLaunchKernelGGL(k_stress_fwd_batch<false>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
 }
-void launch_velocity_fwd_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n) {
-    const Grid g = tiled(g0, 0);
-    hipLaunchKernelGGL(k_velocity_fwd_batch, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
+void launch_velocity_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
+                               PmlCoef pc, size_t n) {
+    const Grid g = tiled_batch(g0, o, 0, nb);
+    hipLaunchKernelGGL(k_velocity_fwd_batch, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
 }
-void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it) {
-    const Grid g = tiled(g0, 1);
-    if (g_opt_early & 1)
-        hipLaunchKernelGGL(k_bwd_a_batch<true>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
+void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
+                        size_t n, int it) {
+    const Grid g = tiled_batch(g0, o, 1, nb);
+    if (o.early & 1)
+        hipLaunchKernelGGL(k_bwd_a_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
     else
-        hipLaunchKernelGGL(k_bwd_a_batch<false>, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
+        hipLaunchKernelGGL(k_bwd_a_batch<false>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
 }
-void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it,
-                        float src_scale, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const Grid g = tiled(g0);
-    auto k = (g_opt_early & 2) ? k_bwd_b_batch<true> : k_bwd_b_batch<false>;
+void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
+                        size_t n, int it, float src_scale, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const Grid g = tiled_batch(g0, o, 1, nb);
+    auto k = (o.early & 2) ? k_bwd_b_batch<true> : k_bwd_b_batch<false>;
     if (ev_start)
-        hipExtLaunchKernelGGL(k, batch_grid(g, nb), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);
+        hipExtLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);
     else
-        hipLaunchKernelGGL(k, batch_grid(g, nb), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it, src_scale);
+        hipLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it, src_scale);
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,

@@ -6,39 +6,55 @@
 
 namespace sepfwi {
 
-void launch_stress_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
-                       int z_src, int x_src, float src_amp, LineRec lr);
-void launch_velocity_fwd(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc);
-void launch_velocity_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, const float *frame_t, int z_src,
-                         int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc);
-void launch_stress_rev(hipStream_t st, const Grid &g, Fields f, Media md, PmlCoef pc, float *frame_t, int z_src,
-                       int x_src, float src_amp, Fields adj, ImgAcc acc);
-void launch_velocity_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
-void launch_stress_adj(hipStream_t st, const Grid &g, Fields adj, PmlMem m, Media md, PmlCoef pc);
-void launch_bwd_velocity(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t,
-                         int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr);
-void launch_bwd_stress(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
-                       int x_src, float src_amp, Fields adj, ImgAcc acc, hipEvent_t ev_start = nullptr,
-                       hipEvent_t ev_stop = nullptr);
-void launch_bwd_a(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, const float *frame_t, Fields adj,
-                  ImgAcc acc, bool acc_nt = false);
-void launch_bwd_b(hipStream_t st, const Grid &g, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t, int z_src,
-                  int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
-                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool acc_nt = false);
-// batched forms (grid.y = shot of the batch; ShotDev table in device memory)
-void launch_stress_fwd_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n,
-                             size_t data_len, int it, float src_scale, bool save);
-void launch_velocity_fwd_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n);
-void launch_bwd_a_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it);
-void launch_bwd_b_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, Media md, PmlCoef pc, size_t n, int it,
-                        float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// Kernel / scheduling options.  sepfwi_set_option() edits the process-wide defaults under a mutex; every cufd call works
+// on ONE snapshot taken at its start (Session::run), which the launchers receive by reference.
+struct KernelOptions {
+    int bz = 2;           // waves (rows) per block of the field kernels
+    int xcd_remap = 1;    // 1: each XCD gets a contiguous band of tiles
+    int bwd_fuse = 2;     // backward step: 0 the reference's four kernels (+ k_inject), 2 cross-chain pairs k_bwd_a / k_bwd_b
+    int line_fuse = 1;    // 1: line receivers are sampled / injected inside the field kernels
+    int pair_fwd = 1;     // 1: forward passes of several shots run concurrently (one stream each, or one batched launch)
+    int fwd_lanes = 3;    // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
+    int early = 0;        // fused backward kernels issue the loads of their second update first: bit 0 k_bwd_a, bit 1 k_bwd_b
+    int rho_fly = 1;      // buoyancy averages rebuilt from the density: bit 0 forward velocity kernel, bit 1 backward kernels
+    int amu_fly = 0;      // harmonic mean of mu rebuilt from mu: bit 0 forward stress kernel, bit 1 backward kernels
+    int rk_lazy = 1;      // adjoint kernels load 1/K only inside the C-PML layers (it is exactly 1 elsewhere)
+    int batch = 2;        // shots of a call advance in batched launches: 0 never (one stream per forward lane), 1 always,
+                          // 2 when at least two backward passes fit the cache budget together
+    int batch_f = 0, batch_b = 0;  // explicit forward / backward batch sizes (0: from batch_mb)
+    int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
+    int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
+    int pipe_bwd = 0;     // 1: backward of shot k overlaps the forward of shot k+1
+    int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
+};
+KernelOptions kernel_options();                       // snapshot of the defaults
+int get_kernel_option(const char *name);              // -1: unknown
+int set_kernel_option(const char *name, int value);   // 0 or -1
+
+void launch_stress_fwd(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
+                       float *frame_t, int z_src, int x_src, float src_amp, LineRec lr);
+void launch_velocity_fwd(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc);
+void launch_velocity_rev(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, Media md, PmlCoef pc,
+                         const float *frame_t, int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc);
+void launch_stress_rev(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, Media md, PmlCoef pc, float *frame_t,
+                       int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc);
+void launch_velocity_adj(hipStream_t st, const Grid &g, const KernelOptions &o, Fields adj, PmlMem m, Media md, PmlCoef pc);
+void launch_stress_adj(hipStream_t st, const Grid &g, const KernelOptions &o, Fields adj, PmlMem m, Media md, PmlCoef pc);
+void launch_bwd_a(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
+                  const float *frame_t, Fields adj, ImgAcc acc);
+void launch_bwd_b(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
+                  int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
+                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// batched forms (one grid over tiles x shots of the batch; ShotDev table in device memory)
+void launch_stress_fwd_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
+                             PmlCoef pc, size_t n, size_t data_len, int it, float src_scale, bool save);
+void launch_velocity_fwd_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
+                               PmlCoef pc, size_t n);
+void launch_bwd_a_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
+                        size_t n, int it);
+void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
+                        size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
-int get_kernel_option_bwd_fuse();
-int get_kernel_option(const char *name);
-// fused forward step (fwd_fused.hip)
-void fwd_fused_tile_shape(int *rows, int *cols);
-void launch_fwd_fused(hipStream_t st, const Grid &g, const FwdFusedArgs &a, int xcd_remap);
-void launch_fwd_march(hipStream_t st, const Grid &g, const FwdFusedArgs &a, LineRec lr, int xcd_remap);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps);
 void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t, int down = 0);
@@ -49,15 +65,5 @@ void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const
                        float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, float *rho, unsigned int *cp2_max_bits);
 void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
                                float *gDen);
-
-// persistent forward time loop (fwd_persist.hip): one launch per shot
-int persist_bands(const Grid &g, int n_cus);            // 0: grid not supported
-size_t persist_halo_floats(const Grid &g, int nb);      // per halo buffer
-bool launch_fwd_persist(hipStream_t st, const Grid &g, const ShotDev &shot, Media md, PmlCoef pc, size_t n, size_t data_len,
-                        float src_scale, int nsteps, int nb, bool save, float *haloV, float *haloS, int *flagV, int *flagS,
-                        int *abort_flag, int rho_fly);
-
-// run-time kernel options ("bz": rows per block 1..16, "xcd_remap": 0/1); returns 0 or -1
-int set_kernel_option(const char *name, int value);
 
 }  // namespace sepfwi

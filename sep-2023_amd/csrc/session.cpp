@@ -35,15 +35,18 @@ static const char *kComp[4] = {"pr", "vx", "vz", "ett"};  // libCUFD.cu:216-223,
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-static bool is_device_ptr(const void *p) {
-    if (!p) return false;
+// Device that owns `p`, or -1 for host memory.  A pointer on ANOTHER device than the session's (the single-process
+// ngpu > 1 path handing GPU-0 tensors to the session of GPU i) is staged like host memory: the kernels only ever touch
+// memory of their own device, peer access is never assumed.
+static int ptr_device(const void *p) {
+    if (!p) return -1;
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // clear: plain host memory is reported as an error on some ROCm versions
-        return false;
+        return -1;
     }
-    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+    return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? attr.device : -1;
 }
 
 static std::string shot_file(const Params &p, int comp, int id) {
@@ -63,8 +66,13 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
                  const std::string &survey_text, const Params &par, const Survey &survey)
     : para_fname_(para_fname), gpu_id_(gpu_id), para_text_(para_text), survey_text_(survey_text), par_(par),
       survey_(survey) {
+    // The data-conditioning keys are dormant in the reference (every call site is commented out, libCUFD.cu:353-457, or acts
+    // on the pressure residual that is never injected, :430-433): computing something else than asked would be worse
+    // than refusing.
+    if (par.if_src_update) throw std::invalid_argument("parameter file: if_src_update is not supported");
     HIP_OK(hipSetDevice(gpu_id_));
     HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
     for (auto &e : ev_) HIP_OK(hipEventCreate(&e));
     for (auto &e : probe_ev_) HIP_OK(hipEventCreate(&e));
 
@@ -96,13 +104,6 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     fld_ = Fields{s, s + n, s + 2 * n, s + 3 * n, s + 4 * n};
     mem_ = PmlMem{s + 5 * n, s + 6 * n, s + 7 * n, s + 8 * n, s + 9 * n, s + 10 * n, s + 11 * n, s + 12 * n};
     adj_ = Fields{s + 13 * n, s + 14 * n, s + 15 * n, s + 16 * n, s + 17 * n};
-    state2_ = dalloc<float>(9 * n);
-    fld2_ = Fields{state2_, state2_ + n, state2_ + 2 * n, state2_ + 3 * n, state2_ + 4 * n};
-    mem2_ = mem_;  // velocity-side memory variables are updated in place; stress-side ones are double-buffered
-    mem2_.dvz_dz = state2_ + 5 * n;
-    mem2_.dvz_dx = state2_ + 6 * n;
-    mem2_.dvx_dz = state2_ + 7 * n;
-    mem2_.dvx_dx = state2_ + 8 * n;
     media_ = dalloc<float>(6 * n);
     HIP_OK(hipMemset(media_, 0, 6 * n * sizeof(float)));
     md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n};
@@ -157,32 +158,6 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         }
         rec_idx_ = dalloc<int>(idx.size());
         HIP_OK(hipMemcpy(rec_idx_, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-        // receivers grouped by owning tile of the fused forward kernel (CSR per shot)
-        int TZ = 1, TX = 1;
-        fwd_fused_tile_shape(&TZ, &TX);
-        const int gx = (g.nx + TX - 1) / TX, gy = (g.nzc + TZ - 1) / TZ;
-        n_tiles_ = gx * gy;
-        std::vector<int> off((size_t)ns * (n_tiles_ + 1), 0), cell(idx.size()), rid(idx.size());
-        for (int i = 0; i < ns; i++) {
-            const Shot &sh = survey_.shots[i];
-            if (!sh.present) continue;
-            int *o = off.data() + (size_t)i * (n_tiles_ + 1);
-            auto tile_of = [&](int r) { return (sh.z_rec[r] / TZ) * gx + sh.x_rec[r] / TX; };
-            for (int r = 0; r < sh.nrec; r++) o[tile_of(r) + 1]++;
-            for (int t = 0; t < n_tiles_; t++) o[t + 1] += o[t];
-            std::vector<int> fill(o, o + n_tiles_);
-            for (int r = 0; r < sh.nrec; r++) {
-                const int k = rec_off_[i] + fill[tile_of(r)]++;
-                cell[k] = sh.z_rec[r] * g.pitch + sh.x_rec[r];
-                rid[k] = r;
-            }
-        }
-        rt_off_ = dalloc<int>(off.size());
-        rt_cell_ = dalloc<int>(cell.size());
-        rt_rec_ = dalloc<int>(rid.size());
-        HIP_OK(hipMemcpy(rt_off_, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(rt_cell_, cell.data(), cell.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(rt_rec_, rid.data(), rid.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     const size_t dlen = (size_t)std::max(1, survey_.max_nrec) * (size_t)par.nSteps;
     data_len_ = dlen;
@@ -196,7 +171,6 @@ Session::~Session() {
     (void)hipSetDevice(gpu_id_);
     (void)hipDeviceSynchronize();
     if (bwd_mem_.dvz_dz) (void)hipFree(bwd_mem_.dvz_dz);
-    if (bwd2_mem_.dvz_dz) (void)hipFree(bwd2_mem_.dvz_dz);
     for (int k = 0; k < 2; k++) {
         if (ev_fwd_[k]) (void)hipEventDestroy(ev_fwd_[k]);
         if (ev_bwd_[k]) (void)hipEventDestroy(ev_bwd_[k]);
@@ -208,8 +182,6 @@ Session::~Session() {
         if (L.syn) (void)hipFree(L.syn);
         if (L.res) (void)hipFree(L.res);
     }
-    if (p_halo_) (void)hipFree(p_halo_);
-    if (p_flags_) (void)hipFree(p_flags_);
     if (d_shots_) (void)hipFree(d_shots_);
     if (d_stf_) (void)hipFree(d_stf_);
     for (XLane &L : xl_) {
@@ -227,6 +199,7 @@ Session::~Session() {
     if (h_io_) (void)hipHostFree(h_io_);
     for (auto &e : ev_) (void)hipEventDestroy(e);
     for (auto &e : probe_ev_) (void)hipEventDestroy(e);
+    if (ev_order_) (void)hipEventDestroy(ev_order_);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -291,21 +264,6 @@ void Session::ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots) 
     }
 }
 
-// Second backward lane: memory variables, adjoint fields and imaging accumulators (zero between calls).
-void Session::ensure_bwd_lane2(hipStream_t st) {
-    const size_t n = cells_;
-    if (bwd2_mem_.dvz_dz) return;
-    float *b = nullptr;
-    HIP_OK(hipMalloc((void **)&b, 18 * n * sizeof(float)));
-    device_bytes_ += (long long)(18 * n * sizeof(float));
-    bwd2_mem_ = PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
-    b += 8 * n;
-    bwd2_adj_ = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
-    b += 5 * n;
-    bwd2_acc_ = ImgAcc{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
-    (void)st;
-}
-
 // Memory variables of the backward pass when it overlaps a forward pass (pipe_bwd), plus the pipeline's events.
 void Session::ensure_bwd_mem() {
     const size_t n = cells_;
@@ -321,6 +279,8 @@ void Session::ensure_bwd_mem() {
 }
 
 void Session::drop_observed() {
+    std::lock_guard<std::mutex> lock(mu_);
+    (void)hipSetDevice(gpu_id_);
     for (auto &kv : obs_) {
         (void)hipFree(kv.second.d_ett);
         device_bytes_ -= (long long)kv.second.bytes;
@@ -355,6 +315,7 @@ void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) 
     e.from_memory = true;
     if (nrec > 0) {
         hipStream_t st = own_stream_;
+        order_after_null_stream(st);  // a HIP `ett` was produced on the caller's (default) stream
         HIP_OK(hipMemcpyAsync(xpose_, ett, want, hipMemcpyDefault, st));
         launch_transpose(st, xpose_, e.d_ett, nrec, nSteps);  // [rec][it] -> [it][rec]
         HIP_OK(hipStreamSynchronize(st));
@@ -411,13 +372,23 @@ const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // the cufd call
 // ------------------------------------------------------------------------------------------------
+// A NULL stream argument means the legacy default stream, which is what torch's default stream is on ROCm: the call's
+// own (non-blocking) stream must not start before the work already queued there -- the Lame maps that produced
+// Lambda/Mu/Den, the zero-fill of the gradient tensors -- has finished.
+void Session::order_after_null_stream(hipStream_t st) {
+    HIP_OK(hipEventRecord(ev_order_, nullptr));
+    HIP_OK(hipStreamWaitEvent(st, ev_order_, 0));
+}
+
 void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf,
                   const float *Lambda, const float *Mu, const float *Den, const float *stf, int calc_id,
                   int group_size, const int *shot_ids, hipStream_t ext_stream, bool async) {
     std::lock_guard<std::mutex> lock(mu_);
     const auto t_begin = std::chrono::steady_clock::now();
     HIP_OK(hipSetDevice(gpu_id_));
+    const KernelOptions opt = kernel_options();  // ONE snapshot for the whole call
     hipStream_t st = ext_stream ? ext_stream : own_stream_;
+    if (!ext_stream) order_after_null_stream(st);
     const Grid &g = g_;
     const bool if_res = (calc_id == 0 || calc_id == 1);  // Parameter.cpp:125-137
     const bool withAdj = (calc_id == 1);
@@ -433,10 +404,11 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     }
 
     // ---- media: boundary arrays -> internal layout, averages, Courant guard ----
+    // inputs that do not live on this session's device (host memory, or another GPU's memory) are staged
     const float *dL = Lambda, *dM = Mu, *dD = Den;
-    if (!is_device_ptr(Lambda)) { HIP_OK(hipMemcpyAsync(in_stage_, Lambda, dense * sizeof(float), hipMemcpyDefault, st)); dL = in_stage_; }
-    if (!is_device_ptr(Mu)) { HIP_OK(hipMemcpyAsync(in_stage_ + dense, Mu, dense * sizeof(float), hipMemcpyDefault, st)); dM = in_stage_ + dense; }
-    if (!is_device_ptr(Den)) { HIP_OK(hipMemcpyAsync(in_stage_ + 2 * dense, Den, dense * sizeof(float), hipMemcpyDefault, st)); dD = in_stage_ + 2 * dense; }
+    if (ptr_device(Lambda) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_, Lambda, dense * sizeof(float), hipMemcpyDefault, st)); dL = in_stage_; }
+    if (ptr_device(Mu) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_ + dense, Mu, dense * sizeof(float), hipMemcpyDefault, st)); dM = in_stage_ + dense; }
+    if (ptr_device(Den) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_ + 2 * dense, Den, dense * sizeof(float), hipMemcpyDefault, st)); dD = in_stage_ + 2 * dense; }
     HIP_OK(hipMemsetAsync(cp2_bits_, 0, sizeof(unsigned int), st));
     launch_model_prep(st, g, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n, cp2_bits_);
     launches_++;
@@ -476,10 +448,10 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     fwd_steps_ = bwd_steps_ = 0;
     std::vector<float> h_gstf;
 
-    // Per-shot context.  Two "lanes" of forward state exist so that the forward passes of two shots can run
-    // concurrently on two streams (their kernel-boundary gaps and tails fill each other: x1.2 on the forward
-    // loops; the two backward passes then run one after the other -- two of them together would not fit the
-    // 256 MB Infinity Cache and lose 15 %, scripts/concurrency_probe.py).
+    // Per-shot context.  Several "lanes" of forward state exist so that the forward passes of several shots can run
+    // concurrently on their own streams (their kernel-boundary gaps and tails fill each other: x1.28 on the forward
+    // loops with three lanes); the backward passes then run one after the other -- two of them together do not fit the
+    // 256 MB Infinity Cache and lose 15 % (scripts/concurrency_probe.py).
     struct ShotCtx {
         int is, id, nrec, comps;
         const Shot *sh;
@@ -488,12 +460,11 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         bool scratch;
         LineRec line;
         float *state;  // [5 fields | 8 memory variables] of this lane
-        Fields fld, fcur;
+        Fields fld;
         PmlMem mem;
         float *frame, *syn, *res;
         hipStream_t st;
     };
-    const int fuse_fwd = par_.fiber ? 0 : get_kernel_option("fwd_fuse");  // the fused forward steps sample exx themselves
     if (withAdj) {  // source-time-function gradients of all shots of the call, one row each
         const size_t need = (size_t)group_size * nSteps;
         if (need > stf_grad_len_) {
@@ -507,18 +478,10 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     }
     if (if_res)  // observed data of every shot of the call resident before the time loops start
         for (int is = 0; is < group_size; is++) (void)observed_ett(shot_ids[is], survey_.shots[shot_ids[is]].nrec, st);
-    int n_lanes = get_kernel_option("pair_fwd") ? get_kernel_option("fwd_lanes") : 1;  // concurrent forward passes
-    if (fuse_fwd != 0 || group_size < 2) n_lanes = 1;
+    int n_lanes = opt.pair_fwd ? opt.fwd_lanes : 1;  // concurrent forward passes
     if (n_lanes > group_size) n_lanes = group_size;
     if (n_lanes > kMaxLanes) n_lanes = kMaxLanes;
-    const bool can_pair = n_lanes >= 2;
-    const bool pair_bwd = can_pair && withAdj && get_kernel_option("pair_bwd") != 0;
-    if (can_pair) ensure_lanes(n_lanes, withAdj);
-    if (pair_bwd) {
-        ensure_bwd_lane2(st);
-        HIP_OK(hipMemsetAsync(bwd2_acc_.lam, 0, 5 * n * sizeof(float), st));
-    }
-    lane2_acc_used_ = false;
+    if (n_lanes < 1) n_lanes = 1;
 
     auto make_ctx = [&](int is, int lane, hipStream_t lane_st) -> ShotCtx {
         ShotCtx c{};
@@ -543,7 +506,6 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         c.state = lane ? xl_[lane].state : state_;
         float *b = c.state;
         c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
-        c.fcur = c.fld;
         c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
         c.frame = lane ? xl_[lane].frame : frame_;
         c.syn = lane ? xl_[lane].syn : syn_;
@@ -559,7 +521,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         for (int k = 0; k < 4; k++)
             if ((c.comps >> k) & 1) HIP_OK(hipMemsetAsync(syn_of(c, k), 0, (size_t)c.nrec * sizeof(float), c.st));
     };
-    // one forward time step, two-kernel form (libCUFD.cu:268-332)
+    // one forward time step (libCUFD.cu:268-332)
     auto forward_step = [&](const ShotCtx &c, int it, bool inl) {
         float *frame_t = withAdj ? c.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
         const float amp = src_scale * c.stf_s[it] * par_.dt;
@@ -571,8 +533,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             lr.d_vz = (c.comps & 4) ? syn_of(c, 2) + c0 : nullptr;
             lr.d_ett = (c.comps & 8) ? syn_of(c, 3) + c0 : nullptr;
         }
-        launch_stress_fwd(c.st, g, c.fld, c.mem, md_, pc_, frame_t, c.sh->z_src, c.sh->x_src, amp, lr);
-        launch_velocity_fwd(c.st, g, c.fld, c.mem, md_, pc_);
+        launch_stress_fwd(c.st, g, opt, c.fld, c.mem, md_, pc_, frame_t, c.sh->z_src, c.sh->x_src, amp, lr);
+        launch_velocity_fwd(c.st, g, opt, c.fld, c.mem, md_, pc_);
         launches_ += 2;
         if (!inl) {
             const size_t col = (size_t)(it + 1) * c.nrec;
@@ -582,121 +544,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     };
     auto forward_last_column = [&](const ShotCtx &c) {
         const size_t col = (size_t)(nSteps - 1) * c.nrec;
-        launch_record(c.st, g, c.fcur, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+        launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
         launches_++;
-    };
-    // persistent forward time loop (fwd_persist.hip): ONE launch per shot, fields register-resident; false = not applicable
-    // (receivers not an inline-sampled line, grid too tall / wide, kernel not co-resident) -> the two-kernel form runs
-    bool stf_on_device = false;
-    auto forward_persist = [&](ShotCtx &c) -> bool {
-        if (!(c.nrec == 0 || (c.line.n > 0 && !(c.comps & 1) && get_kernel_option("line_fuse") != 0))) return false;
-        if (n_cus_ == 0) {
-            hipDeviceProp_t prop;
-            HIP_OK(hipGetDeviceProperties(&prop, gpu_id_));
-            n_cus_ = prop.multiProcessorCount;
-        }
-        const int nb = persist_bands(g, n_cus_);
-        if (nb == 0) return false;
-        const size_t hf = persist_halo_floats(g, nb);
-        if (!p_halo_ || p_nb_ != nb) {
-            if (p_halo_) (void)hipFree(p_halo_);
-            if (p_flags_) (void)hipFree(p_flags_);
-            p_halo_ = nullptr;
-            p_flags_ = nullptr;
-            HIP_OK(hipMalloc((void **)&p_halo_, 2 * hf * sizeof(float)));
-            HIP_OK(hipMalloc((void **)&p_flags_, (size_t)(2 * nb + 1) * 32 * sizeof(int)));
-            p_nb_ = nb;
-        }
-        if (!stf_on_device) {
-            ensure_batch(0, 0, false, group_size);
-            HIP_OK(hipMemcpy(d_stf_, stf_rows.data(), (size_t)group_size * nSteps * sizeof(float), hipMemcpyHostToDevice));
-            stf_on_device = true;
-        }
-        HIP_OK(hipMemsetAsync(p_halo_, 0, 2 * hf * sizeof(float), c.st));
-        HIP_OK(hipMemsetAsync(p_flags_, 0, (size_t)(2 * nb + 1) * 32 * sizeof(int), c.st));
-        ShotDev d{};
-        d.fields = c.state;
-        d.mem = c.state + 5 * n;
-        d.frame = withAdj ? c.frame : nullptr;
-        d.syn = c.syn;
-        d.stf = d_stf_ + (size_t)c.is * nSteps;
-        d.z_src = c.sh->z_src;
-        d.x_src = c.sh->x_src;
-        d.lr_z = c.line.z;
-        d.lr_x0 = c.line.x0;
-        d.lr_n = c.line.n;
-        d.comps = c.comps | (c.line.n > 0 ? 16 : 0);
-        d.nrec = c.nrec;
-        d.src_rxz = (float)c.sh->src_rxz;
-        int *flagV = p_flags_, *flagS = p_flags_ + nb * 32, *abortf = p_flags_ + 2 * nb * 32;
-        if (!launch_fwd_persist(c.st, g, d, md_, pc_, n, data_len_, src_scale, nSteps - 1, nb, withAdj, p_halo_, p_halo_ + hf, flagV,
-                                flagS, abortf, get_kernel_option("rho_fly") & 1))
-            return false;
-        launches_++;
-        if (c.line.n > 0) forward_last_column(c);
-        HIP_OK(hipStreamSynchronize(c.st));
-        int aborted = 0;
-        HIP_OK(hipMemcpy(&aborted, abortf, sizeof(int), hipMemcpyDeviceToHost));
-        if (aborted) throw HipError("persistent forward kernel aborted: a band waited too long for its neighbour");
-        return true;
-    };
-    // fused single-launch forward steps (lane 0 only): 1 = LDS-tiled (fwd_fused.hip), 2 = z-marching (fwd_march.hip)
-    auto forward_fused = [&](ShotCtx &c) {
-        HIP_OK(hipMemsetAsync(state2_, 0, 9 * n * sizeof(float), c.st));
-        // bundles: state_ = [5 fields | 4 stress psi | 4 velocity psi | 5 adjoint], state2_ = [5 fields | 4 stress psi]
-        float *FB[2] = {state_, state2_};
-        float *MB[2] = {state_ + 5 * n, state2_ + 5 * n};
-        const int remap = get_kernel_option("xcd_remap");
-        const bool march = (fuse_fwd == 2);
-        const bool inl = march && c.line.n > 0 && !(c.comps & 1) && get_kernel_option("line_fuse") != 0;
-        FwdFusedArgs a{};
-        a.mv = state_ + 9 * n;
-        a.media = media_;
-        a.cz = pc_.a_z;
-        a.cx = pc_.a_x;
-        a.rt_off = rt_off_ + (size_t)c.id * (n_tiles_ + 1);
-        a.rt_cell = rt_cell_ + rec_off_[c.id];
-        a.rt_rec = rt_rec_ + rec_off_[c.id];
-        a.n = (unsigned)n;
-        a.z_src = c.sh->z_src;
-        a.x_src = c.sh->x_src;
-        const Fields F[2] = {fld_, fld2_};
-        int cur = 0;
-        for (int it = 0; it <= nSteps - 2; it++) {
-            a.fo = FB[cur];
-            a.fn = FB[cur ^ 1];
-            a.mo = MB[cur];
-            a.mn = MB[cur ^ 1];
-            a.frame_t = withAdj ? c.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-            a.src_amp = src_scale * c.stf_s[it] * par_.dt;
-            const size_t col = (size_t)it * c.nrec;  // column `it` = state at the start of step `it`
-            if (!march) {
-                a.d_pr = syn_of(c, 0) + col;
-                a.d_vx = syn_of(c, 1) + col;
-                a.d_vz = syn_of(c, 2) + col;
-                a.d_ett = syn_of(c, 3) + col;
-                a.comps = it >= 1 ? c.comps : 0;
-                launch_fwd_fused(c.st, g, a, remap);
-            } else {
-                LineRec lr{};
-                if (inl && it >= 1) {
-                    lr = c.line;
-                    lr.d_vx = (c.comps & 2) ? syn_of(c, 1) + col : nullptr;
-                    lr.d_vz = (c.comps & 4) ? syn_of(c, 2) + col : nullptr;
-                    lr.d_ett = (c.comps & 8) ? syn_of(c, 3) + col : nullptr;
-                }
-                launch_fwd_march(c.st, g, a, lr, remap);
-                if (!inl) {  // general receivers: sample the new state into column it+1 (as the two-kernel path)
-                    const size_t c1 = (size_t)(it + 1) * c.nrec;
-                    launch_record(c.st, g, F[cur ^ 1], c.nrec, c.rec, syn_of(c, 0) + c1, syn_of(c, 1) + c1, syn_of(c, 2) + c1, syn_of(c, 3) + c1, c.comps);
-                    launches_++;
-                }
-            }
-            cur ^= 1;
-            launches_++;
-        }
-        c.fcur = F[cur];
-        if (!march || inl) forward_last_column(c);
     };
     auto residual = [&](const ShotCtx &c) {
         // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
@@ -765,10 +614,9 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         PmlMem bm;
         Fields adj;
         ImgAcc acc;
-        bool nt, probe;
     };
-    const int fuse_bwd = get_kernel_option_bwd_fuse();
-    const int probe = get_kernel_option("probe");
+    const int fuse_bwd = opt.bwd_fuse;
+    const int probe = opt.probe;
     int n_probe = 0;
     auto backward_init = [&](const BwdLane &L) {
         // adjoint fields + all eight memory variables restart from zero (:503-515); the two pre-loop
@@ -777,7 +625,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         HIP_OK(hipMemsetAsync(L.adj.vz, 0, 5 * n * sizeof(float), L.s));
     };
     auto backward_step = [&](const ShotCtx &c, const BwdLane &L, int it) {
-        const bool inj_inl = c.line.n > 0 && get_kernel_option("line_fuse") != 0;
+        const bool inj_inl = c.line.n > 0 && opt.line_fuse != 0;
         const Shot &sh = *c.sh;
         float *frame_t = c.frame + (size_t)it * 5 * (size_t)g.frame_len;
         float *sg = stf_grad_ + (size_t)c.is * nSteps + it;
@@ -789,27 +637,22 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             lr.res = res_t;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (L.probe && probe > 0 && n_probe < kProbePairs && (it % probe) == 0 && fuse_bwd != 0) {
+        if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0 && fuse_bwd != 0) {
             e0 = probe_ev_[2 * n_probe];
             e1 = probe_ev_[2 * n_probe + 1];
             n_probe++;
         }
         if (fuse_bwd == 2) {
-            launch_bwd_a(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, L.adj, L.acc, L.nt);
-            launch_bwd_b(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1, L.nt);
+            launch_bwd_a(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
+            launch_bwd_b(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
             if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
             launches_ += inj_inl ? 2 : 3;
-        } else if (fuse_bwd == 1) {
-            launch_bwd_velocity(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc, lr);
-            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
-            launch_bwd_stress(L.s, g, c.fcur, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc, e0, e1);
-            launches_ += 3;
-        } else {
-            launch_velocity_rev(L.s, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
-            launch_stress_rev(L.s, g, c.fcur, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
-            launch_velocity_adj(L.s, g, L.adj, L.bm, md_, pc_);
+        } else {  // the reference's launch structure
+            launch_velocity_rev(L.s, g, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
+            launch_stress_rev(L.s, g, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
+            launch_velocity_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
             launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
-            launch_stress_adj(L.s, g, L.adj, L.bm, md_, pc_);
+            launch_stress_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
             launches_ += 5;
         }
     };
@@ -822,63 +665,47 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         n_probe = 0;
     };
-    const int acc_nt_opt = get_kernel_option("acc_nt");
-    // one shot (np == 1) or two shots concurrently, the second on stream 2 with its own adjoint state and accumulators
-    // (added to the first set before the gradients are finalised).  While two passes overlap, the accumulators are
-    // accessed non-temporally: 2 x (5 fields + 5 adjoint fields) + 5 media arrays = 220 MB stay in the Infinity Cache.
-    auto backward = [&](const ShotCtx *c, int np) {
-        BwdLane L[2];
-        L[0] = BwdLane{st, mem_, adj_, acc_, acc_nt_opt == 1 || (acc_nt_opt == 2 && np == 2), true};
-        if (np == 2) {
-            L[1] = BwdLane{stream2_, bwd2_mem_, bwd2_adj_, bwd2_acc_, L[0].nt, false};
-            lane2_acc_used_ = true;
-        }
+    auto backward = [&](const ShotCtx &c) {
+        const BwdLane L{st, mem_, adj_, acc_};
         HIP_OK(hipEventRecord(ev_[2], st));
-        if (np == 2) HIP_OK(hipStreamWaitEvent(stream2_, ev_[2], 0));
-        for (int k = 0; k < np; k++) backward_init(L[k]);
-        for (int it = nSteps - 2; it >= 0; it--)
-            for (int k = 0; k < np; k++) backward_step(c[k], L[k], it);
-        if (np == 2) {
-            HIP_OK(hipEventRecord(ev_join_, stream2_));
-            HIP_OK(hipStreamWaitEvent(st, ev_join_, 0));
-        }
+        backward_init(L);
+        for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
         HIP_OK(hipEventRecord(ev_[3], st));
-        bwd_steps_ += (long long)np * (nSteps - 1);
+        bwd_steps_ += (long long)(nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));
         collect_probes();
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
         bwd_ms_ += ms;
     };
-    auto forward_inline = [&](const ShotCtx &c) { return c.line.n > 0 && !(c.comps & 1) && get_kernel_option("line_fuse") != 0; };
+    auto forward_inline = [&](const ShotCtx &c) { return c.line.n > 0 && !(c.comps & 1) && opt.line_fuse != 0; };
 
     const bool scratch_any = withAdj && !par_.scratch_dir_name.empty();
-    const bool pipelined = withAdj && fuse_fwd == 0 && get_kernel_option("pipe_bwd") != 0 && group_size >= 2 && !scratch_any;
-    // ---------------- batched mode: every launch advances a whole batch of shots (grid.y = shot) ----------------
+    const bool pipelined = withAdj && opt.pipe_bwd != 0 && fuse_bwd == 2 && group_size >= 2 && !scratch_any;
+    // ---------------- batched mode: every launch advances a whole batch of shots ----------------
     // Batch sizes from the Infinity-Cache budget: a forward batch keeps 5 fields per shot + 5 media arrays resident, a
     // backward batch 15 arrays per shot + 5 (2000x500: 7 and 2; a 101x201 notebook problem: all its shots at once).  Where
-    // not even two backward passes fit (2000x1000) the stream mode below is faster: its three forward passes overlap
-    // kernels of different kinds, and its kernels are long enough (13-32 us) not to be launch-bound.
-    const double arr_mb = (double)n * sizeof(float) / 1.0e6, budget = (double)get_kernel_option("batch_mb");
+    // not even two backward passes fit (2000x1000) the stream mode below runs the backward passes one by one.
+    const double arr_mb = (double)n * sizeof(float) / 1.0e6, budget = (double)opt.batch_mb;
     int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
-    const int batch_opt = get_kernel_option("batch");
-    const bool batched = !pipelined && fuse_fwd == 0 && fuse_bwd == 2 && group_size >= 1 && (batch_opt == 1 || (batch_opt == 2 && (withAdj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
+    const bool batched = !pipelined && fuse_bwd == 2 && group_size >= 1 &&
+                         (opt.batch == 1 || (opt.batch == 2 && (withAdj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
+    last_batched_ = batched;
     if (batched) {
-        if (get_kernel_option("batch_f") > 0) Bf = get_kernel_option("batch_f");
-        if (get_kernel_option("batch_b") > 0) Bb = get_kernel_option("batch_b");
+        if (opt.batch_f > 0) Bf = opt.batch_f;
+        if (opt.batch_b > 0) Bb = opt.batch_b;
         Bf = std::max(1, std::min(std::min(Bf, 32), group_size));
         Bb = std::max(1, std::min(Bb, Bf));
-        if (!get_kernel_option("pair_fwd")) Bf = Bb = 1;
+        if (!opt.pair_fwd) Bf = Bb = 1;
         ensure_batch(Bf, withAdj ? Bb : 0, withAdj, group_size);
         HIP_OK(hipMemcpyAsync(d_stf_, stf_rows.data(), (size_t)group_size * nSteps * sizeof(float), hipMemcpyHostToDevice, st));
-        const bool lf = get_kernel_option("line_fuse") != 0;
+        const bool lf = opt.line_fuse != 0;
         auto lane_ctx = [&](int is) {  // shot `is` of the call in its batch lane
             ShotCtx c = make_ctx(is, 0, st);
             const BLane &L = bl_[is % Bf];
             c.state = L.state;
             float *b = c.state;
             c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
-            c.fcur = c.fld;
             c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
             c.frame = L.frame;
             c.syn = L.syn;
@@ -922,8 +749,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             HIP_OK(hipEventRecord(ev_[0], st));
             for (int k = 0; k < nb; k++) forward_init(cx[k]);
             for (int it = 0; it <= nSteps - 2; it++) {
-                launch_stress_fwd_batch(st, g, d_shots_ + is0, nb, md_, pc_, n, data_len_, it, src_scale, withAdj);
-                launch_velocity_fwd_batch(st, g, d_shots_ + is0, nb, md_, pc_, n);
+                launch_stress_fwd_batch(st, g, opt, d_shots_ + is0, nb, md_, pc_, n, data_len_, it, src_scale, withAdj);
+                launch_velocity_fwd_batch(st, g, opt, d_shots_ + is0, nb, md_, pc_, n);
                 launches_ += 2;
                 for (int k = 0; k < nb; k++)
                     if (!(tab[is0 + k].comps & 16)) {  // general receivers: sample the new state into column it+1
@@ -964,8 +791,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                         e1 = probe_ev_[2 * n_probe + 1];
                         n_probe++;
                     }
-                    launch_bwd_a_batch(st, g, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
-                    launch_bwd_b_batch(st, g, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, src_scale, e0, e1);
+                    launch_bwd_a_batch(st, g, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
+                    launch_bwd_b_batch(st, g, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, src_scale, e0, e1);
                     launches_ += 2;
                     for (int k = 0; k < nbb; k++)
                         if (tab[is0 + kb + k].lr_n == 0) {
@@ -994,33 +821,34 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         // Software pipeline over the shots of the call: while the backward pass of shot k runs on the main stream,
         // the forward pass of shot k+1 runs on the second stream in the other lane (fields, memory variables,
         // boundary frames, seismograms, residual are per lane; the backward pass has its own memory variables).
-        // Working set = 5 (forward lane) + 15 (backward) + 5 (media) arrays of 8.8 MB: still inside the 256 MB
+        // Working set = 5 (forward lane) + 15 (backward) + 5 (media) arrays of 9 MB: still inside the 256 MB
         // Infinity Cache, and each pass fills the kernel-boundary gaps and tails of the other.
         ensure_lanes(2, true);
         ensure_bwd_mem();
+        hipStream_t s2 = xl_[1].stream;
         HIP_OK(hipEventRecord(ev_[0], st));
-        HIP_OK(hipStreamWaitEvent(stream2_, ev_[0], 0));
-        ShotCtx cur = make_ctx(0, 0, stream2_);
+        HIP_OK(hipStreamWaitEvent(s2, ev_[0], 0));
+        ShotCtx cur = make_ctx(0, 0, s2);
         {
             const bool inl = forward_inline(cur);
             forward_init(cur);
             for (int it = 0; it <= nSteps - 2; it++) forward_step(cur, it, inl);
             if (inl) forward_last_column(cur);
             residual(cur);
-            HIP_OK(hipEventRecord(ev_fwd_[0], stream2_));
+            HIP_OK(hipEventRecord(ev_fwd_[0], s2));
         }
         for (int k = 0; k < group_size; k++) {
             const bool has_next = k + 1 < group_size;
             ShotCtx nxt{};
             bool inl = false;
             if (has_next) {
-                nxt = make_ctx(k + 1, (k + 1) & 1, stream2_);
+                nxt = make_ctx(k + 1, (k + 1) & 1, s2);
                 inl = forward_inline(nxt);
-                if (k >= 1) HIP_OK(hipStreamWaitEvent(stream2_, ev_bwd_[(k + 1) & 1], 0));  // that lane's previous shot is fully consumed
+                if (k >= 1) HIP_OK(hipStreamWaitEvent(s2, ev_bwd_[(k + 1) & 1], 0));  // that lane's previous shot is fully consumed
                 forward_init(nxt);
             }
             HIP_OK(hipStreamWaitEvent(st, ev_fwd_[k & 1], 0));
-            const BwdLane BL{st, bwd_mem_, adj_, acc_, acc_nt_opt == 1, true};
+            const BwdLane BL{st, bwd_mem_, adj_, acc_};
             backward_init(BL);
             for (int j = 0; j <= nSteps - 2; j++) {
                 backward_step(cur, BL, nSteps - 2 - j);
@@ -1030,7 +858,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             if (has_next) {
                 if (inl) forward_last_column(nxt);
                 residual(nxt);
-                HIP_OK(hipEventRecord(ev_fwd_[(k + 1) & 1], stream2_));
+                HIP_OK(hipEventRecord(ev_fwd_[(k + 1) & 1], s2));
             }
             cur = nxt;
         }
@@ -1038,7 +866,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         fwd_steps_ += (long long)group_size * (nSteps - 1);
         bwd_steps_ += (long long)group_size * (nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));
-        HIP_OK(hipStreamSynchronize(stream2_));
+        HIP_OK(hipStreamSynchronize(s2));
         collect_probes();
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
@@ -1047,29 +875,24 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         bwd_ms_ += ms * (124.0 / 184.0);
     }
 
+    // ---------------- stream mode: up to fwd_lanes forward passes side by side, then their backward passes ----------------
+    if (!pipelined && !batched && n_lanes >= 2) ensure_lanes(n_lanes, withAdj);
     for (int is = 0; is < group_size && !pipelined && !batched;) {
-        const int np = can_pair ? std::min(n_lanes, group_size - is) : 1;
+        const int np = std::min(n_lanes, group_size - is);
         ShotCtx ctx[kMaxLanes];
         ctx[0] = make_ctx(is, 0, st);
         for (int k = 1; k < np; k++) ctx[k] = make_ctx(is + k, k, xl_[k].stream);
 
-        // ---------------- forward time loop(s), libCUFD.cu:268-332 ----------------
+        // forward time loop(s), libCUFD.cu:268-332
         HIP_OK(hipEventRecord(ev_[0], st));
         for (int k = 1; k < np; k++) HIP_OK(hipStreamWaitEvent(xl_[k].stream, ev_[0], 0));  // extra lanes start after everything queued so far
         for (int k = 0; k < np; k++) forward_init(ctx[k]);
-        bool fwd_done = false;
-        if (fuse_fwd == 3) fwd_done = forward_persist(ctx[0]);
-        if (fwd_done) {
-        } else if (fuse_fwd == 1 || fuse_fwd == 2) {
-            forward_fused(ctx[0]);
-        } else {
-            bool inl[kMaxLanes];
-            for (int k = 0; k < np; k++) inl[k] = forward_inline(ctx[k]);
-            for (int it = 0; it <= nSteps - 2; it++)
-                for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
-            for (int k = 0; k < np; k++)
-                if (inl[k]) forward_last_column(ctx[k]);
-        }
+        bool inl[kMaxLanes];
+        for (int k = 0; k < np; k++) inl[k] = forward_inline(ctx[k]);
+        for (int it = 0; it <= nSteps - 2; it++)
+            for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
+        for (int k = 0; k < np; k++)
+            if (inl[k]) forward_last_column(ctx[k]);
         if (if_res)
             for (int k = 0; k < np; k++) residual(ctx[k]);
         for (int k = 1; k < np; k++) {  // join: the main stream continues when the extra lanes are done
@@ -1092,12 +915,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                 scratch_dumps(ctx[k]);
             }
         }
-        if (withAdj) {
-            int k = 0;
-            if (pair_bwd)
-                for (; k + 1 < np; k += 2) backward(&ctx[k], 2);
-            for (; k < np; k++) backward(&ctx[k], 1);
-        }
+        if (withAdj)
+            for (int k = 0; k < np; k++) backward(ctx[k]);
         is += np;
     }
     if (withAdj && grad_stf) {  // rows indexed by local shot position (libCUFD.cu:671-673)
@@ -1106,14 +925,10 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         HIP_OK(hipMemcpy(grad_stf, h_gstf.data(), h_gstf.size() * sizeof(float), hipMemcpyDefault));
     }
 
-    // ---- outputs ----
+    // ---- outputs: written in place when they live on this device, staged otherwise (host memory, another GPU) ----
     if (withAdj) {
-        const bool devL = is_device_ptr(grad_Lambda), devM = is_device_ptr(grad_Mu), devD = is_device_ptr(grad_Den);
+        const bool devL = ptr_device(grad_Lambda) == gpu_id_, devM = ptr_device(grad_Mu) == gpu_id_, devD = ptr_device(grad_Den) == gpu_id_;
         float *oL = devL ? grad_Lambda : grad_stage_, *oM = devM ? grad_Mu : grad_stage_ + dense, *oD = devD ? grad_Den : grad_stage_ + 2 * dense;
-        if (lane2_acc_used_) {  // shots that ran in the second backward lane
-            launch_add_inplace(st, acc_.lam, bwd2_acc_.lam, 5 * n);
-            launches_++;
-        }
         launch_finalize_gradients(st, g, md_, acc_, oL, oM, oD);
         launches_++;
         if (!devL) HIP_OK(hipMemcpyAsync(grad_Lambda, oL, dense * sizeof(float), hipMemcpyDefault, st));
@@ -1127,10 +942,39 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const float mf = (float)(0.5 * sumsq);  // libCUFD.cu:776
         HIP_OK(hipMemcpy(misfit, &mf, sizeof(float), hipMemcpyDefault));
     }
-    if (!async) HIP_OK(hipStreamSynchronize(st));
+    if (!async) {
+        HIP_OK(hipStreamSynchronize(st));
+    } else if (!ext_stream) {  // later work on the default stream sees this call's outputs
+        HIP_OK(hipEventRecord(ev_order_, st));
+        HIP_OK(hipStreamWaitEvent(nullptr, ev_order_, 0));
+    }
     total_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     last_shots_ = group_size;
     last_calc_ = calc_id;
+}
+
+// Test hook (sepfwi_debug_field): one wavefield of one forward lane as the last call left it, dense (nzc, nx).
+void Session::copy_field(int lane, int which, float *out) {
+    std::lock_guard<std::mutex> lock(mu_);
+    HIP_OK(hipSetDevice(gpu_id_));
+    if (!out || which < 0 || which > 9) throw std::invalid_argument("debug_field: which must be 0..9");
+    const float *base = nullptr;
+    if (which >= 5) {  // adjoint fields: one set per session (stream mode) or per backward lane (batched mode)
+        if (last_batched_) {
+            if (lane < 0 || lane >= (int)bl_.size() || !bl_[lane].bwd) throw std::invalid_argument("debug_field: no such backward lane");
+            base = bl_[lane].bwd + (8 + (which - 5)) * cells_;
+        } else {
+            base = adj_.vz + (size_t)(which - 5) * cells_;
+        }
+    } else if (last_batched_) {
+        if (lane < 0 || lane >= (int)bl_.size() || !bl_[lane].state) throw std::invalid_argument("debug_field: no such lane");
+        base = bl_[lane].state + (size_t)which * cells_;
+    } else {
+        if (lane < 0 || lane >= kMaxLanes || (lane > 0 && !xl_[lane].state)) throw std::invalid_argument("debug_field: no such lane");
+        base = (lane ? xl_[lane].state : state_) + (size_t)which * cells_;
+    }
+    HIP_OK(hipMemcpy2D(out, (size_t)g_.nx * sizeof(float), base, (size_t)g_.pitch * sizeof(float), (size_t)g_.nx * sizeof(float),
+                       (size_t)g_.nzc, hipMemcpyDefault));
 }
 
 void Session::stats(sepfwi_stats *out) const {
@@ -1152,30 +996,31 @@ void Session::stats(sepfwi_stats *out) const {
 // registry
 // ------------------------------------------------------------------------------------------------
 static std::mutex g_reg_mu;
-static std::map<std::pair<std::string, int>, std::unique_ptr<Session>> g_sessions;
+static std::map<std::pair<std::string, int>, std::shared_ptr<Session>> g_sessions;
 
-Session &get_session(const std::string &para_fname, int gpu_id) {
+std::shared_ptr<Session> get_session(const std::string &para_fname, int gpu_id) {
     const std::string ptext = read_first_line(para_fname);
     Params par = parse_params(ptext);
     const std::string stext = read_first_line(par.survey_fname);
     std::lock_guard<std::mutex> lock(g_reg_mu);
     auto key = std::make_pair(para_fname, gpu_id);
     auto it = g_sessions.find(key);
-    if (it != g_sessions.end() && it->second->matches(ptext, stext)) return *it->second;
-    if (it != g_sessions.end()) g_sessions.erase(it);
+    if (it != g_sessions.end() && it->second->matches(ptext, stext)) return it->second;
+    if (it != g_sessions.end()) g_sessions.erase(it);  // a thread still inside run() keeps its own reference
     Survey sv = parse_survey(stext, par.nPml);
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (gpu_id < 0 || gpu_id >= ndev)
         throw HipError("gpu_id " + std::to_string(gpu_id) + " out of range: " + std::to_string(ndev) + " HIP device(s) visible");
-    g_sessions[key] = std::unique_ptr<Session>(new Session(para_fname, gpu_id, ptext, stext, par, sv));
-    return *g_sessions[key];
+    auto sp = std::make_shared<Session>(para_fname, gpu_id, ptext, stext, par, sv);
+    g_sessions[key] = sp;
+    return sp;
 }
 
-Session *find_session(const std::string &para_fname, int gpu_id) {
+std::shared_ptr<Session> find_session(const std::string &para_fname, int gpu_id) {
     std::lock_guard<std::mutex> lock(g_reg_mu);
     auto it = g_sessions.find(std::make_pair(para_fname, gpu_id));
-    return it == g_sessions.end() ? nullptr : it->second.get();
+    return it == g_sessions.end() ? nullptr : it->second;
 }
 
 void release_all_sessions() {
@@ -1184,8 +1029,12 @@ void release_all_sessions() {
 }
 
 void invalidate_observed_all() {
-    std::lock_guard<std::mutex> lock(g_reg_mu);
-    for (auto &kv : g_sessions) kv.second->drop_observed();
+    std::vector<std::shared_ptr<Session>> all;
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        for (auto &kv : g_sessions) all.push_back(kv.second);
+    }
+    for (auto &sp : all) sp->drop_observed();
 }
 
 }  // namespace sepfwi

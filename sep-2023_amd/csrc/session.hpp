@@ -12,6 +12,7 @@
 #include "../../include/sepfwi.h"
 #include "config.hpp"
 #include "fwi_types.hpp"
+#include "kernels.hpp"
 
 namespace sepfwi {
 
@@ -35,6 +36,9 @@ class Session {
     void drop_observed();
     // observed axial strain of one shot from memory ([nrec][nSteps] like the files; host or device pointer)
     void set_observed(int shot_id, const float *ett, int nrec, int nSteps);
+    // test hook: wavefield `which` (0..4 vz, vx, szz, sxx, sxz; 5..9 their adjoint twins) of forward lane `lane` as left
+    // by the last call, dense (nz - nPad, nx) row-major, host or device pointer
+    void copy_field(int lane, int which, float *out);
     const Params &params() const { return par_; }
 
   private:
@@ -43,7 +47,7 @@ class Session {
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void ensure_bwd_mem();
-    void ensure_bwd_lane2(hipStream_t st);
+    void order_after_null_stream(hipStream_t st);
 
     struct ObsEntry {
         float *d_ett = nullptr;  // [nSteps][nrec]
@@ -61,6 +65,7 @@ class Session {
     std::mutex mu_;
     hipStream_t own_stream_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_order_ = nullptr;
     static constexpr int kProbePairs = 64;
     hipEvent_t probe_ev_[2 * kProbePairs] = {};
     double probe_us_ = 0.0;
@@ -70,7 +75,7 @@ class Session {
 
     size_t cells_ = 0, data_len_ = 0;
     // extra forward lanes (lane 0 = state_/frame_/syn_/res_ on the call's stream): fields + memories, frames, seismograms,
-    // residual, stream, join event.  Lane 1 doubles as the second backward lane's stream.
+    // residual, stream, join event
     static constexpr int kMaxLanes = 4;
     struct XLane {
         float *state = nullptr, *frame = nullptr, *syn = nullptr, *res = nullptr;
@@ -78,8 +83,6 @@ class Session {
         hipEvent_t join = nullptr;
     };
     XLane xl_[kMaxLanes];
-    hipStream_t &stream2_ = xl_[1].stream;
-    hipEvent_t &ev_join_ = xl_[1].join;
     hipEvent_t ev_fwd_[2] = {nullptr, nullptr}, ev_bwd_[2] = {nullptr, nullptr};
     PmlMem bwd_mem_{};  // backward-pass memory variables of the pipelined mode
     size_t stf_grad_len_ = 0;
@@ -93,19 +96,7 @@ class Session {
     int shots_cap_ = 0;
     float *d_stf_ = nullptr;
     size_t d_stf_len_ = 0;
-    // persistent forward time loop (fwd_fuse=3): halo exchange buffers, step flags, abort flag
-    float *p_halo_ = nullptr;
-    int *p_flags_ = nullptr;
-    int p_nb_ = 0, n_cus_ = 0;
-    PmlMem bwd2_mem_{};  // second backward lane (pair_bwd)
-    Fields bwd2_adj_{};
-    ImgAcc bwd2_acc_{};
-    bool lane2_acc_used_ = false;
-    float *state2_ = nullptr;  // second copy of the 5 fields + 4 stress-side memory variables (fused forward)
-    int *rt_off_ = nullptr, *rt_cell_ = nullptr, *rt_rec_ = nullptr;
-    int n_tiles_ = 0;
-    Fields fld2_{};
-    PmlMem mem2_{};
+    bool last_batched_ = false;
     float *state_ = nullptr, *media_ = nullptr, *acc_buf_ = nullptr, *in_stage_ = nullptr, *grad_stage_ = nullptr;
     float *frame_ = nullptr, *syn_ = nullptr, *res_ = nullptr, *xpose_ = nullptr, *stf_grad_ = nullptr, *h_io_ = nullptr;
     double *scal_ = nullptr;
@@ -124,8 +115,10 @@ class Session {
     int last_shots_ = 0, last_calc_ = -1;
 };
 
-Session &get_session(const std::string &para_fname, int gpu_id);
-Session *find_session(const std::string &para_fname, int gpu_id);
+// The registry hands out shared ownership: a session that another thread is still running survives being replaced
+// (parameter file rewritten) or released.
+std::shared_ptr<Session> get_session(const std::string &para_fname, int gpu_id);
+std::shared_ptr<Session> find_session(const std::string &para_fname, int gpu_id);
 void release_all_sessions();
 void invalidate_observed_all();
 

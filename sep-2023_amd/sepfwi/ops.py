@@ -37,6 +37,30 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.detach().contiguous()
 
 
+_DIMS_CACHE = {}
+
+
+def _para_dims(para_fname):
+    """(nz, nx, nSteps) of the one-line parameter JSON (fwi_utils.py:46-83), cached by mtime.  The reference passes raw
+    data_ptr<float>()s with no size anywhere (Src/Torch_Fwi.cpp:55-58); here a tensor of the wrong shape is an error
+    before the library reads or writes past it."""
+    import json
+    import os
+    try:
+        key = (str(para_fname), os.stat(para_fname).st_mtime_ns)
+    except OSError:
+        return None          # the library reports the missing file (SEPFWI_EIO)
+    if key not in _DIMS_CACHE:
+        try:
+            with open(para_fname) as fp:
+                j = json.loads(fp.readline())
+            _DIMS_CACHE.clear()
+            _DIMS_CACHE[key] = (int(j["nz"]), int(j["nx"]), int(j["nSteps"]))
+        except (ValueError, KeyError, TypeError):
+            return None      # the library reports the malformed file (SEPFWI_EJSON)
+    return _DIMS_CACHE[key]
+
+
 class _FwiOps:
     """Module object: fwi_ops.forward / backward / obscalc."""
 
@@ -49,32 +73,57 @@ class _FwiOps:
         Lambda, Mu, Den, Stf = _f32c(Lambda, "Lambda"), _f32c(Mu, "Mu"), _f32c(Den, "Den"), _f32c(Stf, "Stf")
         if Lambda.dim() != 2 or Lambda.shape != Mu.shape or Lambda.shape != Den.shape:
             raise ValueError("Lambda, Mu, Den must be 2-D tensors of one shape (nz_pad, nx_pad)")
+        if Mu.device != Lambda.device or Den.device != Lambda.device:
+            raise ValueError("Lambda, Mu, Den must live on one device")
         ids = np.ascontiguousarray(np.asarray(shot_ids.cpu() if torch.is_tensor(shot_ids) else shot_ids, dtype=np.int32))
+        dims = _para_dims(para_fname)
+        if dims is not None:
+            nz, nx, nSteps = dims
+            if tuple(Lambda.shape) != (nz, nx):
+                raise ValueError("Lambda/Mu/Den are %s but the parameter file says (nz, nx) = (%d, %d)" % (tuple(Lambda.shape), nz, nx))
+            if Stf.dim() != 2 or Stf.shape[1] != nSteps:
+                raise ValueError("Stf must be (nSrc, nSteps = %d), got %s" % (nSteps, tuple(Stf.shape)))
+            if ids.size and (int(ids.min()) < 0 or int(ids.max()) >= Stf.shape[0]):
+                raise ValueError("Shot_ids must index rows of Stf (0..%d), got %d..%d" % (Stf.shape[0] - 1, int(ids.min()), int(ids.max())))
+        gpu_id = int(gpu_id)
         dev = out_device if out_device is not None else Lambda.device
+        # gradients are allocated where the session writes them in place: on ITS GPU when the model lives on a GPU
+        # (also another one: single-process ngpu > 1), on the host for the reference's CPU tensors
+        gdev = torch.device("cuda", gpu_id) if Lambda.is_cuda else torch.device("cpu")
         misfit = torch.zeros(1, dtype=torch.float32)
         gL = gM = gD = gS = None
         if calc_id == 1:
-            gL = torch.zeros(Lambda.shape, dtype=torch.float32, device=dev)
+            gL = torch.zeros(Lambda.shape, dtype=torch.float32, device=gdev)
             gM = torch.zeros_like(gL)
             gD = torch.zeros_like(gL)
             gS = torch.zeros((int(ids.size), Stf.shape[1]), dtype=torch.float32)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        stream = None
-        if Lambda.is_cuda:
-            stream = C.c_void_p(torch.cuda.current_stream(Lambda.device).cuda_stream)
+        stream = None        # NULL = the legacy default stream: the library orders itself behind it
+        if Lambda.is_cuda and Lambda.device.index == gpu_id:
+            cs = torch.cuda.current_stream(Lambda.device).cuda_stream
+            stream = C.c_void_p(cs) if cs else None
+        elif Lambda.is_cuda:
+            torch.cuda.synchronize(Lambda.device)   # the model was produced on another GPU: finished before it is staged
+        if Stf.is_cuda:
+            torch.cuda.synchronize(Stf.device)      # read with a blocking copy inside the library
         rc = L.sepfwi_cufd_stream(ptr(misfit), ptr(gL), ptr(gM), ptr(gD), ptr(gS), ptr(Lambda), ptr(Mu), ptr(Den),
-                                  ptr(Stf), int(calc_id), int(gpu_id), int(ids.size), C.c_void_p(ids.ctypes.data),
+                                  ptr(Stf), int(calc_id), gpu_id, int(ids.size), C.c_void_p(ids.ctypes.data),
                                   str(para_fname).encode(), stream, 0)
         _native.check(rc)
+        if calc_id == 1 and gL.device != dev:
+            gL, gM, gD = gL.to(dev), gM.to(dev), gD.to(dev)
         return misfit, gL, gM, gD, gS
 
-    def _device_for(self, t: torch.Tensor, i: int) -> int:
+    def _device_for(self, t: torch.Tensor, i: int, ngpu: int = 1) -> int:
+        """HIP device of shot block `i` of `ngpu`: the pinned one (bench, tests), this rank's under torch.distributed,
+        the tensor's own device for a single block, device i otherwise (the reference's omp thread i <-> GPU i,
+        Src/Torch_Fwi.cpp:71-95)."""
         if self.device_override is not None:
             return int(self.device_override)
-        if t.is_cuda:
-            return t.device.index or 0
         if _dist.active():
             return _dist.local_device_index()
+        if ngpu == 1 and t.is_cuda:
+            return t.device.index or 0
         return i
 
     # -- reference surface -------------------------------------------------------------------
@@ -96,15 +145,15 @@ class _FwiOps:
             parts = [self._cufd(1, self._device_for(Lambda, 0), Lambda, Mu, Den, Stf, ids, para_fname)]
         else:
             with ThreadPoolExecutor(max_workers=ngpu) as ex:   # one host thread per GPU, ctypes drops the GIL
-                futs = [ex.submit(self._cufd, 1, self._device_for(Lambda, i), Lambda, Mu, Den, Stf,
+                futs = [ex.submit(self._cufd, 1, self._device_for(Lambda, i, ngpu), Lambda, Mu, Den, Stf,
                                   ids[bars[i]:bars[i + 1]], para_fname, Lambda.device) for i in range(ngpu)]
                 parts = [f.result() for f in futs]
         m, gL, gM, gD, gS0 = parts[0]
-        for p in parts[1:]:              # host sum of Torch_Fwi.cpp:96-101
+        for p in parts[1:]:              # sum of Torch_Fwi.cpp:96-101 (every part already sits on Lambda's device)
             m = m + p[0]
-            gL += p[1].to(gL.device)
-            gM += p[2].to(gM.device)
-            gD += p[3].to(gD.device)
+            gL += p[1]
+            gM += p[2]
+            gD += p[3]
         gS = torch.zeros_like(_f32c(Stf, "Stf").cpu())   # zeros_like(th_stf), rows by local shot position
         gS[: gS0.shape[0]] = gS0
         return [m, gL, gM, gD, gS]
@@ -131,7 +180,7 @@ class _FwiOps:
             self._cufd(2, self._device_for(Lambda, 0), Lambda, Mu, Den, Stf, ids, para_fname)
         else:
             with ThreadPoolExecutor(max_workers=ngpu) as ex:
-                futs = [ex.submit(self._cufd, 2, self._device_for(Lambda, i), Lambda, Mu, Den, Stf,
+                futs = [ex.submit(self._cufd, 2, self._device_for(Lambda, i, ngpu), Lambda, Mu, Den, Stf,
                                   ids[bars[i]:bars[i + 1]], para_fname) for i in range(ngpu)]
                 [f.result() for f in futs]
         return None
@@ -146,6 +195,17 @@ class _FwiOps:
         dev = self.device_override if self.device_override is not None else int(gpu_id)
         _native.check(_native.lib().sepfwi_set_observed(str(para_fname).encode(), dev, int(shot_id), C.c_void_p(ett.data_ptr()),
                                                         int(ett.shape[0]), int(ett.shape[1])))
+
+    def debug_field(self, para_fname, which, lane=0, gpu_id=0):
+        """Test hook (sepfwi_debug_field): wavefield 0..4 (vz, vx, szz, sxx, sxz) / adjoint 5..9 of a forward lane as the
+        last call left it, (nz - nPad, nx) float32."""
+        import json
+        with open(para_fname) as fp:
+            j = json.loads(fp.readline())
+        out = torch.empty((int(j["nz"]) - int(j["nPad"]), int(j["nx"])), dtype=torch.float32)
+        dev = self.device_override if self.device_override is not None else int(gpu_id)
+        _native.check(_native.lib().sepfwi_debug_field(str(para_fname).encode(), dev, int(lane), int(which), C.c_void_p(out.data_ptr())))
+        return out
 
     def stats(self, para_fname, gpu_id=0):
         st = _native.Stats()

@@ -1,4 +1,5 @@
 """Seeded synthetic set-ups shared by the parity tests (inputs only; no reference code)."""
+import contextlib
 import json
 import os
 
@@ -17,7 +18,8 @@ def smooth_random(rng, shape, lo, hi, passes=8):
 
 
 def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, dt=1.0e-3, f0=25.0,
-                 hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None, src_x=None, das_fiber="horizontal"):
+                 hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None, src_x=None, das_fiber="horizontal",
+                 rec_x=None, stf=None):
     """Writes para/survey JSON under workdir and returns everything a test needs.
     Models: `true` (with anomalies) and `init` (smooth), both (nz, nx) float32, plus padded versions."""
     rng = np.random.default_rng(seed)
@@ -48,13 +50,13 @@ def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, 
     ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir, das_fiber=das_fiber)
     src_x = np.linspace(6, nx - 7, nshots).round().astype(int) if src_x is None else np.asarray(src_x, dtype=int)
     src_zs = np.full(nshots, src_z, dtype=int)
-    rec_x = np.arange(4, nx - 4, nrec_stride).astype(int)
+    rec_x = np.arange(4, nx - 4, nrec_stride).astype(int) if rec_x is None else np.asarray(rec_x, dtype=int)
     rec_zs = np.full(rec_x.shape, (nz - 6) if rec_z is None else rec_z, dtype=int)
     if das_fiber == "vertical":   # a borehole fibre: one column, consecutive depths
         rec_zs = np.arange(4, nz - 4, nrec_stride).astype(int)
         rec_x = np.full(rec_zs.shape, nx // 2 + 3, dtype=int)
     ft.surveyGen(src_zs, src_x, rec_zs, rec_x, survey_fname)
-    stf = ft.sourceGene(f0, nSteps, dt)
+    stf = ft.sourceGene(f0, nSteps, dt) if stf is None else np.asarray(stf)
     Stf = torch.tensor(stf, dtype=torch.float32).repeat(nshots, 1)
     Shot_ids = torch.arange(nshots, dtype=torch.int32)
     opt = dict(nz=nz, nx=nx, nz_orig=nz, nx_orig=nx, nPml=nPml, nPad=nPad, para_fname=para_fname)
@@ -71,8 +73,50 @@ def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, 
                 para=json.load(open(para_fname)), survey=json.load(open(survey_fname)))
 
 
+def sustained_source(f0, nSteps, dt, period=0.31):
+    """Ricker wavelets (fwi_utils.sourceGene) re-fired every `period` seconds with changing sign and size: keeps the
+    wavefield alive over thousands of time steps, so a long run tests more than the decay of one pulse."""
+    base = ft.sourceGene(f0, nSteps, dt)
+    out = np.zeros(nSteps)
+    k, shift = 0, 0
+    while shift < nSteps:
+        out[shift:] += base[: nSteps - shift] * (1.0 if k % 2 == 0 else -0.7) * (1.0 + 0.13 * (k % 5))
+        k += 1
+        shift = int(round(k * period / dt))
+    return out
+
+
+LONG_RUN = dict(nz=150, nx=300, nPml=20, nSteps=4000, nshots=1, f0=15.0, seed=11, src_x=[120], rec_x=list(range(100, 164)))
+
+
+def make_long_problem(workdir):
+    """The 4000-step problem of tests/golden/oracle_long4000.npz (scripts/make_golden_long.py): 300 x 150 cells + 20-cell
+    layers, one shot with a sustained source, a 64-channel DAS line (the fused in-kernel sampling / injection path)."""
+    kw = dict(LONG_RUN)
+    return make_problem(workdir, hetero=True, stf=sustained_source(kw["f0"], kw["nSteps"], 1.0e-3), **kw)
+
+
 def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     d = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a))
+
+
+# defaults of struct KernelOptions (csrc/kernels.hpp); `probe` is bench.py's business
+OPTION_DEFAULTS = dict(bz=2, xcd_remap=1, bwd_fuse=2, line_fuse=1, pair_fwd=1, fwd_lanes=3, early=0, rho_fly=1, amu_fly=0,
+                       rk_lazy=1, batch=2, batch_f=0, batch_b=0, batch_mb=200, batch_order=1, pipe_bwd=0)
+
+
+@contextlib.contextmanager
+def kernel_options(**opts):
+    """Process-wide kernel options for the duration of a block, defaults restored afterwards."""
+    from sepfwi import _native
+    L = _native.lib()
+    try:
+        for k, v in opts.items():
+            _native.check(L.sepfwi_set_option(k.encode(), int(v)))
+        yield
+    finally:
+        for k, v in OPTION_DEFAULTS.items():
+            L.sepfwi_set_option(k.encode(), int(v))

@@ -1,6 +1,9 @@
-"""Two ranks (gloo) sharing the one GPU of the test box: the real HIP operator under torch.distributed.
-Checks that the sharded run (each rank its contiguous block of shots, one all-reduce) returns on every rank what a
-single process computes for all shots."""
+"""The real HIP operator on more than one shot block (-m gpu).
+
+On the one-GPU test box: two gloo ranks sharing the GPU, the single-process `ngpu = 2` thread path pinned to that GPU, and
+`bench.py --gpus 2` spawning its own ranks.  Where at least two devices are visible (the driver's 8-GPU node): RCCL ranks,
+one GPU each, against the single-process result with exactly one collective per operator call; the single-process
+`ngpu = 2` path with one session per GPU, fed CPU tensors and tensors resident on GPU 0 (cross-device staging)."""
 import os
 import socket
 import sys
@@ -71,3 +74,130 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, oracle, hip_ops):
     # gStf: rank 0 holds its own block (shot 0), rows by local position; other ranks zeros
     assert P.rel_l2(res[0][5][:1], ref[4].numpy()[:1]) <= 1e-6
     assert np.all(res[1][5] == 0.0)
+
+
+def _single_process_reference(work, hip_ops, nshots=4, nSteps=160):
+    import json
+    pb = P.make_problem(os.path.join(work, "single"), hetero=True, nSteps=nSteps, nshots=nshots)
+    para = dict(pb["para"]); para["data_dir_name"] = os.path.join(work, "Data")
+    json.dump(para, open(pb["para_fname"], "w"))
+    os.makedirs(para["data_dir_name"], exist_ok=True)
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    lam, mu, den = pb["lame_init"]
+    return pb, hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+
+
+def test_thread_path_ngpu2_pinned_to_one_gpu(tmp_path, oracle, hip_ops):
+    """`ngpu = 2` without torch.distributed: two host threads, two shot blocks (the reference's OpenMP model,
+    Src/Torch_Fwi.cpp:59-101), here both pinned to the box's only GPU: partition, per-block calls and the sum."""
+    pb, ref = _single_process_reference(str(tmp_path), hip_ops)
+    lam, mu, den = pb["lame_init"]
+    hip_ops.device_override = 0
+    try:
+        for dev_inputs in (False, True):
+            a = [t.cuda() for t in (lam, mu, den)] if dev_inputs else [lam, mu, den]
+            got = hip_ops.backward(a[0], a[1], a[2], pb["Stf"], 2, pb["Shot_ids"], pb["para_fname"])
+            assert abs(float(got[0]) - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+            for k in (1, 2, 3):
+                assert got[k].device == a[0].device
+                assert P.rel_l2(got[k].cpu().numpy(), ref[k].numpy()) <= 1e-5
+            # gStf: GPU 0's block only (shots 0, 1 of 4), rows by local position (Torch_Fwi.cpp:102-103)
+            assert P.rel_l2(got[4].numpy()[:2], ref[4].numpy()[:2]) <= 1e-6 and np.all(got[4].numpy()[2:] == 0.0)
+    finally:
+        hip_ops.device_override = None
+
+
+def _rccl_worker(rank, world, port, workdir, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "sep-2023_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as td
+    torch.cuda.set_device(rank)
+    td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    ncoll = [0]
+    real = td.all_reduce
+
+    def counting(*a, **k):
+        ncoll[0] += 1
+        return real(*a, **k)
+    td.all_reduce = counting
+    import json
+    import problems as P2
+    from sepfwi import fwi_ops
+    pb = P2.make_problem(os.path.join(workdir, "rank%d" % rank), hetero=True, nSteps=160, nshots=4)
+    para = dict(pb["para"]); para["data_dir_name"] = os.path.join(workdir, "Data")
+    json.dump(para, open(pb["para_fname"], "w"))
+    lam, mu, den = [t.cuda() for t in pb["lame_init"]]
+    m, gL, gM, gD, gS = fwi_ops.backward(lam, mu, den, pb["Stf"], world, pb["Shot_ids"], pb["para_fname"])
+    q.put((rank, float(m), gL.cpu().numpy(), gM.cpu().numpy(), gD.cpu().numpy(), gS.numpy(), ncoll[0]))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_ranks_match_single_process(tmp_path, oracle, hip_ops):
+    """One rank per GPU, backend nccl (= RCCL over xGMI): every rank ends with the single-process gradient, and the
+    operator call issues exactly ONE collective (north star).  Needs >= 2 devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least 2 HIP devices")
+    world = min(torch.cuda.device_count(), 4)
+    pb, ref = _single_process_reference(str(tmp_path), hip_ops)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for r in res:
+        assert r[6] == 1
+        assert abs(r[1] - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+        for k in (2, 3, 4):
+            assert P.rel_l2(r[k], ref[k - 1].numpy()) <= 1e-5
+    assert np.all(res[1][5] == 0.0)
+
+
+def test_thread_path_ngpu2_on_two_gpus(tmp_path, oracle, hip_ops):
+    """Single process, `ngpu = 2`, one session per GPU.  CPU tensors (the reference's usage) and tensors resident on
+    GPU 0: GPU 1's session stages the model from GPU 0 and its gradients return to GPU 0.  Needs >= 2 devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least 2 HIP devices")
+    pb, ref = _single_process_reference(str(tmp_path), hip_ops)
+    lam, mu, den = pb["lame_init"]
+    for dev_inputs in (False, True):
+        a = [t.cuda(0) for t in (lam, mu, den)] if dev_inputs else [lam, mu, den]
+        got = hip_ops.backward(a[0], a[1], a[2], pb["Stf"], 2, pb["Shot_ids"], pb["para_fname"])
+        st0, st1 = hip_ops.stats(pb["para_fname"], 0), hip_ops.stats(pb["para_fname"], 1)
+        assert st0["bwd_steps"] > 0 and st1["bwd_steps"] > 0          # both GPUs really propagated
+        assert abs(float(got[0]) - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+        for k in (1, 2, 3):
+            assert got[k].device == a[0].device
+            assert P.rel_l2(got[k].cpu().numpy(), ref[k].numpy()) <= 1e-5
+
+
+def _run_bench(extra, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--nz", "120", "--nx", "200",
+                          "--nsteps", "300", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun must measure TWO ranks (it used to measure one silently): here as a
+    rehearsal on one GPU (gloo, both ranks on device 0), and over RCCL where two devices exist."""
+    one = _run_bench(["--gpus", "1"])
+    two = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["parallelism"] == "shots x2" and two["value"] > 0
+    if torch.cuda.device_count() >= 2:
+        rc = _run_bench(["--gpus", "2"])
+        assert rc["n_gpus"] == 2 and rc["value"] > 0

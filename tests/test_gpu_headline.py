@@ -1,0 +1,170 @@
+"""Headline-scale parity (-m gpu): what the small oracle problems cannot show.
+
+* 4000 time steps (BASELINE.json's sweep length) against the CPU oracle on a grid it can afford, from a committed
+  golden file (scripts/make_golden_long.py): seismograms <= 1e-4, misfit 1e-4, gradients <= 1e-3 -- in the stream
+  structure (what runs at 2000 x 1000) and in the batched structure (what the heuristics pick for this grid).
+* The full 2000 x 1000 x 4000 configuration through a size-independent property: after the
+  backward pass the reverse-time reconstruction has been run back to time step 0 and must have returned to the zero
+  initial state to <= 1e-5 of the peak forward amplitude.
+* BASELINE.json configs[1] (2000 x 500, 2000 steps, forward only): full-size properties plus an oracle-checked cropped
+  twin of the same model, spacing, time step and source.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "oracle_long4000.npz")
+
+
+def _digest(pb):
+    h = hashlib.sha256()
+    for t in list(pb["lame_true"]) + list(pb["lame_init"]) + [pb["Stf"]]:
+        h.update(np.ascontiguousarray(t.numpy()).tobytes())
+    return h.hexdigest()
+
+
+def _interior(pb, f, nz, nx):
+    n = pb["nPml"]
+    return f[n:n + nz, n:n + nx]
+
+
+@pytest.mark.timeout(600)
+def test_long_run_4000_steps_matches_oracle(tmp_path, hip_ops):
+    from sepfwi import utils as ft
+    G = np.load(GOLDEN)
+    pb = P.make_long_problem(str(tmp_path))
+    assert _digest(pb) == str(G["digest"]), "problem generator drifted: regenerate with scripts/make_golden_long.py"
+    nz, nx, nPml, nS = P.LONG_RUN["nz"], P.LONG_RUN["nx"], pb["nPml"], pb["nSteps"]
+    crop = lambda g: g[nPml:nPml + nz, nPml:nPml + nx + 1]
+    lt, mt, dt_ = pb["lame_true"]
+    lam, mu, den = pb["lame_init"]
+    for name, opts in (("streams", dict(batch=0)), ("batched", dict())):
+        with P.kernel_options(**opts):
+            hip_ops.release()
+            hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+            ett = ft.read_shot_gather(pb["data_dir"], "ett", 0, nS)
+            assert ett.shape == G["obs_ett"].shape
+            e_obs = P.rel_l2(ett, G["obs_ett"])
+            assert e_obs <= 1e-4, (name, e_obs)
+            late = slice(3 * nS // 4, nS)                       # the last quarter of the run on its own
+            assert np.abs(G["obs_ett"][:, late]).max() > 0.05 * np.abs(G["obs_ett"]).max()   # the source is still firing
+            assert P.rel_l2(ett[:, late], G["obs_ett"][:, late]) <= 1e-4, name
+            G["obs_ett"].tofile(os.path.join(pb["data_dir"], "Shot_ett0.bin"))   # the oracle's observed data, bit for bit
+            hip_ops.release()
+            m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+            assert abs(float(m) - float(G["misfit"])) <= 1e-4 * float(G["misfit"]), (name, float(m), float(G["misfit"]))
+            for key, g in (("gLambda", gL), ("gMu", gM), ("gDen", gD)):
+                g = g.numpy()
+                r = G[key]
+                e = P.rel_l2(crop(g), r)
+                assert e <= 1e-3, (name, key, e)
+                assert np.abs(crop(g) - r).max() <= 1e-3 * np.abs(r).max(), (name, key)
+                z = g.copy()
+                crop(z)[...] = 0
+                assert not z.any(), (name, key)                  # nothing outside the window the oracle writes
+            assert P.rel_l2(gS.numpy()[0], G["gStf"]) <= 1e-3, name
+            # reverse-time reconstruction ran back to step 0: the physical interior has returned to the zero initial state
+            peak_v = max(float(G["obs_peak"][1]), float(G["obs_peak"][2]))
+            peak_s = float(G["obs_peak"][0])
+            for which in range(5):
+                f = _interior(pb, hip_ops.debug_field(pb["para_fname"], which).numpy(), nz, nx)
+                assert np.abs(f).max() <= 1e-5 * (peak_v if which < 2 else peak_s), (name, which, np.abs(f).max())
+
+
+@pytest.mark.timeout(900)
+def test_headline_2000x1000x4000_reconstruction_returns_to_zero(tmp_path, hip_ops):
+    """BASELINE.json configs[2] at FULL size and length (one shot): forward, boundary saving, 3999 reverse-time steps.
+    The oracle cannot go there; the property can -- and it is sharp: any asymmetry between the forward and the reverse
+    kernels, a wrong frame slot, a lost source sample leaves a wavefield behind instead of round-off."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from sepfwi import utils as ft
+    nS = 4000
+    pb = bench.setup_problem(str(tmp_path), 1000, 2000, nS, 3)
+    ids = torch.tensor([1], dtype=torch.int32)                   # the shot in the middle of the line
+    lt, mt, dt_ = [t.cuda() for t in pb["lame_true"]]
+    lam, mu, den = [t.cuda() for t in pb["lame_init"]]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, ids, pb["para_fname"])
+    data_dir = str(tmp_path / "Data")
+    d = {c: ft.read_shot_gather(data_dir, c, 1, nS) for c in ("pr", "vx", "vz")}
+    peak_v = max(np.abs(d["vx"]).max(), np.abs(d["vz"]).max())
+    peak_s = np.abs(d["pr"]).max()                                # szz + sxx along the line through the source
+    assert peak_v > 0 and peak_s > 0
+    nP, nz, nx = pb["nPml"], 1000, 2000
+    inner = lambda f: f[nP:nP + nz, nP:nP + nx]
+    # forward only (misfit call): the final wavefield is NOT small -- the property below is not vacuous
+    hip_ops.forward(lam, mu, den, pb["Stf"], 0, ids, pb["para_fname"])
+    end_v = max(np.abs(inner(hip_ops.debug_field(pb["para_fname"], k).numpy())).max() for k in (0, 1))
+    assert end_v > 1e-3 * peak_v
+    m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    st = hip_ops.stats(pb["para_fname"], 0)
+    assert st["fwd_steps"] == nS - 1 and st["bwd_steps"] == nS - 1
+    assert float(m) > 0 and all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in (gL, gM, gD))
+    worst = {}
+    for which, name in enumerate(("vz", "vx", "szz", "sxx", "sxz")):
+        f = inner(hip_ops.debug_field(pb["para_fname"], which).numpy())
+        worst[name] = float(np.abs(f).max() / (peak_v if which < 2 else peak_s))
+    print("reconstructed field at step 0 / peak forward amplitude:", worst)
+    assert max(worst.values()) <= 1e-5, worst
+
+
+@pytest.mark.timeout(900)
+def test_config1_shape_2000x500_forward_only(tmp_path, hip_ops, oracle):
+    """BASELINE.json configs[1]: 2000 x 500 Marmousi-style model, one shot, 2000 steps, forward only."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from sepfwi import utils as ft
+    nS = 2000
+    pb = bench.setup_problem(str(tmp_path / "full"), 500, 2000, nS, 3)
+    ids = torch.tensor([1], dtype=torch.int32)
+    lt, mt, dt_ = [t.cuda() for t in pb["lame_true"]]
+    data_dir = str(tmp_path / "full" / "Data")
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, ids, pb["para_fname"])
+    st = hip_ops.stats(pb["para_fname"], 0)
+    assert st["fwd_steps"] == nS - 1 and st["bwd_steps"] == 0
+    d1 = {c: ft.read_shot_gather(data_dir, c, 1, nS).copy() for c in ("pr", "vx", "vz", "ett")}
+    for c, a in d1.items():
+        assert a.shape == (pb["nrec"], nS) and np.isfinite(a).all() and np.abs(a).max() > 0, c
+        assert np.all(a[:, 0] == 0.0), c                                   # column 0 stays zero (Appendix A-7)
+    assert np.array_equal(d1["ett"][1:], d1["vx"][1:] - d1["vx"][:-1])       # consecutive channels: exx_r = vx_r - vx_(r-1), exactly
+    assert np.abs(d1["vz"][:, nS // 2:]).max() > 0                           # the wavefield is alive in the second half
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, ids, pb["para_fname"])       # bit-identical repeat
+    for c in d1:
+        assert np.array_equal(ft.read_shot_gather(data_dir, c, 1, nS), d1[c]), c
+    hip_ops.obscalc(lt, mt, dt_, 2.0 * pb["Stf"], 1, ids, pb["para_fname"])   # linearity in the source (x2 is exact in float32)
+    for c in d1:
+        assert P.rel_l2(ft.read_shot_gather(data_dir, c, 1, nS), 2.0 * d1[c]) <= 1e-6, c
+    hip_ops.release()
+
+    # cropped twin: the 200 x 100 window of the SAME model under the source, same spacing / time step / wavelet, 700 steps,
+    # against the CPU oracle (all four components)
+    nz, nx, nPml, nSt = 100, 200, pb["nPml"], 700
+    (vp, vs, rho), _ = bench.marmousi_style(500, 2000)
+    x0 = 1000 - nx // 2
+    win = [a[:nz, x0:x0 + nx] for a in (vp, vs, rho)]
+    nPad = ft.nPad_for(nz, nPml)
+    work = tmp_path / "crop"
+    os.makedirs(work, exist_ok=True)
+    para_fname, survey_fname = str(work / "para_file.json"), str(work / "survey_file.json")
+    ft.paraGen(nz + 2 * nPml + nPad, nx + 2 * nPml, 10.0, 10.0, nSt, 1.0e-3, 10.0, nPml, nPad, para_fname, survey_fname, str(work / "Data"))
+    rec_x = np.arange(10, nx - 10)
+    ft.surveyGen(np.array([2]), np.array([nx // 2]), np.full(rec_x.shape, 2), rec_x, survey_fname)
+    pad = [torch.tensor(ft.padding_numpy_array(a, nPml, nPad)) for a in win]
+    lam = ((pad[0] ** 2 - 2.0 * pad[1] ** 2) * pad[2] / 1e6).contiguous()
+    mu = (pad[1] ** 2 * pad[2] / 1e6).contiguous()
+    Stf = torch.tensor(ft.sourceGene(10.0, nSt, 1.0e-3), dtype=torch.float32).reshape(1, -1)
+    import json
+    ref = oracle.cufd(lam.numpy(), mu.numpy(), pad[2].numpy(), Stf.numpy(), 2, [0], json.load(open(para_fname)),
+                      json.load(open(survey_fname)))["syn"][0]
+    hip_ops.obscalc(lam.cuda(), mu.cuda(), pad[2].contiguous().cuda(), Stf, 1, torch.tensor([0], dtype=torch.int32), para_fname)
+    for k, c in enumerate(("pr", "vx", "vz", "ett")):
+        got = ft.read_shot_gather(str(work / "Data"), c, 0, nSt)
+        assert P.rel_l2(got, ref[k]) <= 1e-4, (c, P.rel_l2(got, ref[k]))

@@ -204,3 +204,15 @@ def test_cpml_profiles_are_trivial_outside_the_layers(N, nPml, dh, f0, dt):
     for prof, one in ((K, 1.0), (Kh, 1.0), (a, 0.0), (ah, 0.0)):
         assert np.all(prof[~layer] == one)
     assert np.any(K[layer] != 1.0) and np.any(a[layer] != 0.0)
+
+
+def test_bench_launcher_command_line():
+    """`python bench.py --gpus N` with no WORLD_SIZE turns itself into the N-rank job: the driver's own command line."""
+    import bench
+    cmd = bench.launcher_cmd(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"], port=29517)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    free = bench.launcher_cmd(2, [])
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536

@@ -129,3 +129,27 @@ def test_oracle_vertical_fibre_gradient_is_consistent_with_finite_differences(or
         out[fiber] = (fd, float((r0["gDen"] * d).sum()))
     for fiber, (fd, gd) in out.items():
         assert abs(fd - gd) <= 0.05 * abs(gd), (fiber, fd, gd)
+
+
+def test_long_run_golden_is_what_the_oracle_computes(tmp_path, oracle):
+    """tests/golden/oracle_long4000.npz (4000 time steps; the GPU test compares against it) is the oracle's output on
+    tests/problems.py LONG_RUN: same problem digest, same observed gather, same misfit and gradients, bit for bit."""
+    import hashlib
+    import problems as P
+    G = np.load(os.path.join(GOLDEN, "oracle_long4000.npz"))
+    pb = P.make_long_problem(str(tmp_path))
+    h = hashlib.sha256()
+    for t in list(pb["lame_true"]) + list(pb["lame_init"]) + [pb["Stf"]]:
+        h.update(np.ascontiguousarray(t.numpy()).tobytes())
+    assert h.hexdigest() == str(G["digest"])
+    ids = pb["Shot_ids"].numpy()
+    lam, mu, den = [t.numpy() for t in pb["lame_true"]]
+    obs = oracle.cufd(lam, mu, den, pb["Stf"].numpy(), 2, ids, pb["para"], pb["survey"])["syn"]
+    assert np.array_equal(obs[0, 3], G["obs_ett"])
+    lam, mu, den = [t.numpy() for t in pb["lame_init"]]
+    ref = oracle.cufd(lam, mu, den, pb["Stf"].numpy(), 1, ids, pb["para"], pb["survey"], obs=obs)
+    n, nz, nx = pb["nPml"], P.LONG_RUN["nz"], P.LONG_RUN["nx"]
+    assert ref["misfit"] == float(G["misfit"])
+    for k in ("gLambda", "gMu", "gDen"):
+        assert np.array_equal(ref[k][n:n + nz, n:n + nx + 1], G[k]), k
+    assert np.array_equal(ref["gStf"][0], G["gStf"])
