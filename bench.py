@@ -145,7 +145,7 @@ def main():
         # bare `python bench.py --gpus N`: nothing has touched the GPU yet, so become the launcher of N ranks (child
         # process; its exit code is ours) instead of silently measuring one GPU
         import subprocess
-        if torch.cuda.device_count() < args.gpus:
+        if not args.share_gpu and torch.cuda.device_count() < args.gpus:
             raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
