@@ -89,9 +89,10 @@ __device__ __forceinline__ Cell my_cell(const Grid &g, int *shot = nullptr) {
 
 // 4-point harmonic mean of mu at the staggered corner (z+1/2, x+1/2): aveMuInit, utilities.cu:124-137.  amu_fly: rebuilt
 // from mu (three neighbour taps that hit the cache) instead of streaming a second array; single precision with the
-// hardware reciprocal (<= 1 ulp each), i.e. within 4e-7 of the stored double-precision value -- the forward and the
-// reverse-time kernels evaluate the same expression, so reconstruction still cancels exactly.  A zero mu gives
-// 1/0 = inf -> 4/inf = 0, the reference's fluid rule.  Valid on [2, n-3]^2 (every cell the kernels update).
+// hardware reciprocal (<= 1 ulp each), i.e. within 4e-7 of the reference's double-precision value.  While the option is
+// on, k_model_prep stores exactly THIS value in md.ave_mu as well, so kernels that read the array (the backward ones,
+// by default) and kernels that rebuild it see the same bits and reverse-time reconstruction cancels as before.  A zero
+// mu gives 1/0 = inf -> 4/inf = 0, the reference's fluid rule.  Valid on [2, n-3]^2 (every cell the kernels update).
 __device__ __forceinline__ float ave_mu_at(const Grid &g, const Media &md, size_t i, float mu0) {
     if (g.amu_fly) {
         const float s = (__builtin_amdgcn_rcpf(mu0) + __builtin_amdgcn_rcpf(md.mu[i + g.pitch])) +
@@ -766,7 +767,7 @@ __global__ void k_transpose(const float *__restrict__ in, float *__restrict__ ou
 __global__ void k_model_prep(Grid g, const float *__restrict__ Lam_in, const float *__restrict__ Mu_in,
                              const float *__restrict__ Den_in, float *__restrict__ lam, float *__restrict__ mu,
                              float *__restrict__ ave_mu, float *__restrict__ byc_a, float *__restrict__ byc_b,
-                             float *__restrict__ rho, unsigned int *__restrict__ cp2_max_bits) {
+                             float *__restrict__ rho, unsigned int *__restrict__ cp2_max_bits, int amu_fly) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int z = blockIdx.y * blockDim.y + threadIdx.y;
     float cp2 = 0.0f;
@@ -790,7 +791,10 @@ __global__ void k_model_prep(Grid g, const float *__restrict__ Lam_in, const flo
                 const double c = (double)Mu_in[si + 1] * 1e6;
                 const double d = (double)Mu_in[si + g.nx + 1] * 1e6;
                 const float bf = (float)b, cf = (float)c, df = (float)d;
-                if (!(M == 0.0f || bf == 0.0f || cf == 0.0f || df == 0.0f))
+                if (amu_fly)  // the value the stress kernels rebuild on the fly (ave_mu_at): ONE definition of the average per session
+                    am = 4.0f * __builtin_amdgcn_rcpf((__builtin_amdgcn_rcpf(M) + __builtin_amdgcn_rcpf(bf)) +
+                                                      (__builtin_amdgcn_rcpf(cf) + __builtin_amdgcn_rcpf(df)));
+                else if (!(M == 0.0f || bf == 0.0f || cf == 0.0f || df == 0.0f))
                     am = (float)(4.0 / (1.0 / a + 1.0 / (double)bf + 1.0 / (double)cf + 1.0 / (double)df));
                 ba = (float)(2.0 / (double)(Den_in[si + g.nx] + D));
                 bb = (float)(2.0 / (double)(Den_in[si + 1] + D));
@@ -1078,10 +1082,11 @@ void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int
     hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, in, out, rows, cols);
 }
 
-void launch_model_prep(hipStream_t st, const Grid &g, const float *Lam_in, const float *Mu_in, const float *Den_in,
-                       float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, float *rho, unsigned int *cp2_max_bits) {
+void launch_model_prep(hipStream_t st, const Grid &g, const KernelOptions &o, const float *Lam_in, const float *Mu_in,
+                       const float *Den_in, float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, float *rho,
+                       unsigned int *cp2_max_bits) {
     hipLaunchKernelGGL(k_model_prep, dim3((g.nx + 63) / 64, (g.nz + 3) / 4), dim3(64, 4), 0, st, g, Lam_in, Mu_in, Den_in,
-                       lam, mu, ave_mu, byc_a, byc_b, rho, cp2_max_bits);
+                       lam, mu, ave_mu, byc_a, byc_b, rho, cp2_max_bits, o.amu_fly != 0 ? 1 : 0);
 }
 
 void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,

@@ -410,7 +410,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     if (ptr_device(Mu) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_ + dense, Mu, dense * sizeof(float), hipMemcpyDefault, st)); dM = in_stage_ + dense; }
     if (ptr_device(Den) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_ + 2 * dense, Den, dense * sizeof(float), hipMemcpyDefault, st)); dD = in_stage_ + 2 * dense; }
     HIP_OK(hipMemsetAsync(cp2_bits_, 0, sizeof(unsigned int), st));
-    launch_model_prep(st, g, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n, cp2_bits_);
+    launch_model_prep(st, g, opt, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n, cp2_bits_);
     launches_++;
     {
         unsigned int bits = 0;
