@@ -84,6 +84,20 @@ Survey parse_survey(const std::string &text, int nPml) {
             sh.x_rec[r] = xr.arr[r].as_int("x_rec[]") + nPml;
         }
         if (js.has("src_rxz")) sh.src_rxz = js.at("src_rxz").as_number("src_rxz");
+        if (js.has("das_sensitivity")) {
+            const JsonValue &ds = js.at("das_sensitivity");
+            if (ds.kind != JsonValue::Array || (int)ds.arr.size() < sh.nrec)
+                throw std::runtime_error("survey JSON: das_sensitivity must hold nrec rows of 6 numbers for " + kv.first);
+            sh.sens.resize(3 * (size_t)sh.nrec);
+            for (int r = 0; r < sh.nrec; r++) {
+                const JsonValue &row = ds.arr[r];
+                if (row.kind != JsonValue::Array || row.arr.size() != 6)
+                    throw std::runtime_error("survey JSON: das_sensitivity rows need 6 numbers (exx, exz, -, ezz, -, -) for " + kv.first);
+                sh.sens[3 * r + 0] = (float)row.arr[0].as_number("das_sensitivity[][0]");  // exx
+                sh.sens[3 * r + 1] = (float)row.arr[3].as_number("das_sensitivity[][3]");  // ezz
+                sh.sens[3 * r + 2] = (float)row.arr[1].as_number("das_sensitivity[][1]");  // exz
+            }
+        }
         if (sh.nrec > s.max_nrec) s.max_nrec = sh.nrec;
         s.shots[id] = std::move(sh);
     }

@@ -23,6 +23,10 @@ struct Shot {
     int nrec = 0;
     std::vector<int> z_rec, x_rec;  // shifted by +nPml (Src_Rec.cu:107-115)
     double src_rxz = 1.0;           // RSXXZZ default, Src_Rec.cu:259-264
+    // optional key "das_sensitivity" (nrec x 6, the Numba solver's layout: column 0 weighs exx, 3 ezz, 1 exz,
+    // MOD/elasticSolver.py:152-153,276): per-channel directional sensitivities, stored as (s_xx, s_zz, s_xz) triples.
+    // Empty: straight fibre along x or z (para key "das_fiber").
+    std::vector<float> sens;
     bool present = false;
 };
 

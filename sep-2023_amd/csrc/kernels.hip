@@ -691,7 +691,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
 // ---------------------------------------------------------------------------------------------
 __global__ void k_record(Grid g, Fields f, int nrec, const int *__restrict__ rec_idx /* z*pitch+x */,
                          float *__restrict__ d_pr, float *__restrict__ d_vx, float *__restrict__ d_vz,
-                         float *__restrict__ d_ett, int comps, int fiber) {
+                         float *__restrict__ d_ett, int comps, int fiber, const float *__restrict__ sens) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const int i = rec_idx[r];
@@ -700,21 +700,44 @@ __global__ void k_record(Grid g, Fields f, int nrec, const int *__restrict__ rec
     if (comps & 2) d_vx[r] = vx;
     const float vz = f.vz[i];
     if (comps & 4) d_vz[r] = vz;
+    if (!(comps & 8)) return;
+    if (sens) {
+        // directional channel: ett = s0 exx + s3 ezz + s1 exz (MOD/elasticSolver.py:266-276), strains as one-cell differences in
+        // units of "strain x dx" like recording_exx (the z-differences carry dx/dz)
+        const float k = g.dx * g.rdz;
+        const float exx = vx - f.vx[i - 1];
+        const float ezz = (vz - f.vz[i - g.pitch]) * k;
+        const float exz = 0.5f * ((f.vx[i + g.pitch] - vx) * k + (f.vz[i + 1] - vz));
+        d_ett[r] = sens[3 * r] * exx + sens[3 * r + 1] * ezz + sens[3 * r + 2] * exz;
+        return;
+    }
     // axial strain over one cell, not divided by the spacing (utilities.cu:600-601): exx for a horizontal fibre,
     // ezz (recording_ezz, utilities.cu:620-629) for a vertical one
-    if (comps & 8) d_ett[r] = fiber ? vz - f.vz[i - g.pitch] : vx - f.vx[i - 1];
+    d_ett[r] = fiber ? vz - f.vz[i - g.pitch] : vx - f.vx[i - 1];
 }
 
 // res_injection_exx: vx_adj(z,x) += r ; vx_adj(z,x-1) -= r.  Adjacent channels share cells, so the
 // two statements are applied through float atomics (the reference's plain +=/-= is racy there,
-// utilities.cu:613-614).  Atomic order only permutes two adds per cell.
+// utilities.cu:613-614).  Atomic order only permutes a few adds per cell.  With `sens`: the transpose of the
+// directional channel above.
 __global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, const float *__restrict__ res_t,
-                         int down /* 0: horizontal fibre, else the pitch: vertical fibre (res_injection_ezz, utilities.cu:632-641) */) {
+                         int down /* 0: horizontal fibre, else the pitch: vertical fibre (res_injection_ezz, utilities.cu:632-641) */,
+                         const float *__restrict__ sens, int pitch, float dx_dz) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const int i = rec_idx[r];
     const float v = res_t[r];
-    if (down) {
+    if (sens) {
+        const float a = sens[3 * r] * v, b = sens[3 * r + 1] * dx_dz * v, c = 0.5f * sens[3 * r + 2] * v;
+        atomicAdd(&adj.vx[i], a);
+        atomicAdd(&adj.vx[i - 1], -a);
+        atomicAdd(&adj.vz[i], b);
+        atomicAdd(&adj.vz[i - pitch], -b);
+        atomicAdd(&adj.vx[i + pitch], c * dx_dz);
+        atomicAdd(&adj.vx[i], -(c * dx_dz));
+        atomicAdd(&adj.vz[i + 1], c);
+        atomicAdd(&adj.vz[i], -c);
+    } else if (down) {
         atomicAdd(&adj.vz[i], v);
         atomicAdd(&adj.vz[i - down], -v);
     } else {
@@ -1058,15 +1081,16 @@ void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, 
 }
 
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
-                   float *d_vz, float *d_ett, int comps) {
+                   float *d_vz, float *d_ett, int comps, const float *sens) {
     if (nrec <= 0) return;
     hipLaunchKernelGGL(k_record, dim3((nrec + 255) / 256), dim3(256), 0, st, g, f, nrec, rec_idx, d_pr, d_vx, d_vz, d_ett,
-                       comps, g.fiber);
+                       comps, g.fiber, sens);
 }
 
-void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t, int down) {
+void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const int *rec_idx, const float *res_t, const float *sens) {
     if (nrec <= 0) return;
-    hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t, down);
+    hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t, g.fiber ? g.pitch : 0,
+                       sens, g.pitch, g.dx * g.rdz);
 }
 
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,

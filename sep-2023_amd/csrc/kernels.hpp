@@ -56,8 +56,10 @@ void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
-                   float *d_vz, float *d_ett, int comps);
-void launch_inject(hipStream_t st, Fields adj, int nrec, const int *rec_idx, const float *res_t, int down = 0);
+                   float *d_vz, float *d_ett, int comps, const float *sens = nullptr);
+// sens: null (straight fibre along x, or along z when g.fiber) or nrec x 3 directional sensitivities (s_xx, s_zz, s_xz)
+void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const int *rec_idx, const float *res_t,
+                   const float *sens = nullptr);
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
                      double *sumsq);
 void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);

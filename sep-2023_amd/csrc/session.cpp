@@ -148,9 +148,11 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
             if (!sh.present) continue;
             if (sh.z_src < 2 || sh.z_src > g.nzc - 3 || sh.x_src < 2 || sh.x_src > g.nx - 3)
                 throw std::runtime_error("survey: source of shot " + std::to_string(i) + " lies outside the computed grid");
+            const bool dir = !sh.sens.empty();  // directional channels reach one cell in every direction
             for (int r = 0; r < sh.nrec; r++) {
                 // the axial-strain difference reaches one cell to the left (horizontal fibre) or up (vertical fibre)
-                if (sh.z_rec[r] < (par.fiber ? 1 : 0) || sh.z_rec[r] >= g.nzc || sh.x_rec[r] < (par.fiber ? 0 : 1) || sh.x_rec[r] >= g.nx)
+                if (sh.z_rec[r] < ((par.fiber || dir) ? 1 : 0) || sh.z_rec[r] >= g.nzc - (dir ? 1 : 0) ||
+                    sh.x_rec[r] < ((par.fiber && !dir) ? 0 : 1) || sh.x_rec[r] >= g.nx - (dir ? 1 : 0))
                     throw std::runtime_error("survey: receiver " + std::to_string(r) + " of shot " + std::to_string(i) +
                                              " lies outside the grid");
                 idx[(size_t)rec_off_[i] + r] = sh.z_rec[r] * g.pitch + sh.x_rec[r];
@@ -158,6 +160,17 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         }
         rec_idx_ = dalloc<int>(idx.size());
         HIP_OK(hipMemcpy(rec_idx_, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        bool any_sens = false;
+        for (int i = 0; i < ns; i++) any_sens = any_sens || (survey_.shots[i].present && !survey_.shots[i].sens.empty());
+        if (any_sens) {  // (s_xx, s_zz, s_xz) per channel, same offsets as rec_idx_
+            std::vector<float> sv(3 * idx.size(), 0.0f);
+            for (int i = 0; i < ns; i++) {
+                const Shot &sh = survey_.shots[i];
+                if (sh.present && !sh.sens.empty()) std::copy(sh.sens.begin(), sh.sens.end(), sv.begin() + 3 * (size_t)rec_off_[i]);
+            }
+            sens_ = dalloc<float>(sv.size());
+            HIP_OK(hipMemcpy(sens_, sv.data(), sv.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     const size_t dlen = (size_t)std::max(1, survey_.max_nrec) * (size_t)par.nSteps;
     data_len_ = dlen;
@@ -457,6 +470,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const Shot *sh;
         const int *rec;
         const float *stf_s, *d_obs;
+        const float *sens;  // directional sensitivities of this shot's channels (device) or null
         bool scratch;
         LineRec line;
         float *state;  // [5 fields | 8 memory variables] of this lane
@@ -490,13 +504,14 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         c.sh = &survey_.shots[c.id];
         c.nrec = c.sh->nrec;
         c.rec = rec_idx_ + rec_off_[c.id];
+        c.sens = (sens_ && !c.sh->sens.empty()) ? sens_ + 3 * (size_t)rec_off_[c.id] : nullptr;
         c.stf_s = stf_rows.data() + (size_t)is * nSteps;
         c.d_obs = if_res ? observed_ett(c.id, c.nrec, st) : nullptr;
         c.scratch = withAdj && !par_.scratch_dir_name.empty();  // libCUFD.cu:732-752
         c.comps = if_res ? (c.scratch ? 9 : 8) : 15;
         // horizontal line of consecutive channels inside the computed region?
         const Shot &sh = *c.sh;
-        bool is_line = par_.fiber == 0 && c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
+        bool is_line = par_.fiber == 0 && !c.sens && c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
         for (int r = 1; r < c.nrec && is_line; r++) is_line = (sh.z_rec[r] == sh.z_rec[0] && sh.x_rec[r] == sh.x_rec[0] + r);
         if (is_line) {
             c.line.z = sh.z_rec[0];
@@ -538,13 +553,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         launches_ += 2;
         if (!inl) {
             const size_t col = (size_t)(it + 1) * c.nrec;
-            launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+            launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
             launches_++;
         }
     };
     auto forward_last_column = [&](const ShotCtx &c) {
         const size_t col = (size_t)(nSteps - 1) * c.nrec;
-        launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+        launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
         launches_++;
     };
     auto residual = [&](const ShotCtx &c) {
@@ -645,13 +660,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         if (fuse_bwd == 2) {
             launch_bwd_a(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
             launch_bwd_b(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
-            if (!inj_inl) launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
+            if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
             launches_ += inj_inl ? 2 : 3;
         } else {  // the reference's launch structure
             launch_velocity_rev(L.s, g, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
             launch_stress_rev(L.s, g, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
             launch_velocity_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
-            launch_inject(L.s, L.adj, c.nrec, c.rec, res_t, par_.fiber ? g.pitch : 0);
+            launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
             launch_stress_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
             launches_ += 5;
         }
@@ -756,7 +771,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                     if (!(tab[is0 + k].comps & 16)) {  // general receivers: sample the new state into column it+1
                         const ShotCtx &c = cx[k];
                         const size_t col = (size_t)(it + 1) * c.nrec;
-                        launch_record(st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps);
+                        launch_record(st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
                         launches_++;
                     }
             }
@@ -798,7 +813,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                         if (tab[is0 + kb + k].lr_n == 0) {
                             const ShotCtx &c = cx[kb + k];
                             const Fields adj = Fields{bl_[k].bwd + 8 * n, bl_[k].bwd + 9 * n, bl_[k].bwd + 10 * n, bl_[k].bwd + 11 * n, bl_[k].bwd + 12 * n};
-                            launch_inject(st, adj, c.nrec, c.rec, c.res + (size_t)it * c.nrec, par_.fiber ? g.pitch : 0);
+                            launch_inject(st, g, adj, c.nrec, c.rec, c.res + (size_t)it * c.nrec, c.sens);
                             launches_++;
                         }
                 }

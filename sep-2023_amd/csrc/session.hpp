@@ -102,6 +102,7 @@ class Session {
     double *scal_ = nullptr;
     unsigned int *cp2_bits_ = nullptr;
     int *rec_idx_ = nullptr;
+    float *sens_ = nullptr;  // directional DAS sensitivities (3 per channel) or null
     std::vector<int> rec_off_;
     Fields fld_{}, adj_{};
     PmlMem mem_{};

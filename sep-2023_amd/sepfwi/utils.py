@@ -65,9 +65,13 @@ def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname
         json.dump(para, fp)
 
 
-def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Src_Weights=None, Src_rxz=None, Rec_rxz=None):
+def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Src_Weights=None, Src_rxz=None, Rec_rxz=None, Das_sensitivity=None):
     """Write the one-line survey JSON: every shot shares the receiver list; indices are UNPADDED grid
-    indices (fwi_utils.py:87-124)."""
+    indices (fwi_utils.py:87-124).
+    Das_sensitivity (extension): (nrec, 6) directional sensitivities of the DAS channels in the layout of
+    the reference's Numba solver (DAS_Waveform_Modeling/src/elasticSolver.py:152-153,276): column 0 weighs exx, column 3
+    ezz, column 1 exz -- ett = s0 exx + s3 ezz + s1 exz, for shaped / dipping fibres.  Omitted: a straight fibre along x
+    (or z, parameter key das_fiber), the reference's CUDA behaviour; the key is only written when given."""
     z_src = np.asarray(z_src).tolist()
     x_src = np.asarray(x_src).tolist()
     z_rec = np.asarray(z_rec).tolist()
@@ -82,6 +86,11 @@ def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Src_Weights=None, Src_rx
             shot["src_rxz"] = Src_rxz[i]
         if Rec_rxz is not None:
             shot["rec_rxz"] = np.asarray(Rec_rxz).tolist()
+        if Das_sensitivity is not None:
+            ds = np.asarray(Das_sensitivity, dtype=float)
+            if ds.shape != (len(x_rec), 6):
+                raise ValueError("Das_sensitivity must be (nrec, 6): exx, exz, -, ezz, -, - (elasticSolver.py:152-153)")
+            shot["das_sensitivity"] = ds.tolist()
         survey["shot%d" % i] = shot
     with open(survey_fname, "w") as fp:
         json.dump(survey, fp)

@@ -19,7 +19,7 @@ def smooth_random(rng, shape, lo, hi, passes=8):
 
 def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, dt=1.0e-3, f0=25.0,
                  hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None, src_x=None, das_fiber="horizontal",
-                 rec_x=None, stf=None):
+                 rec_x=None, stf=None, das_sensitivity=None):
     """Writes para/survey JSON under workdir and returns everything a test needs.
     Models: `true` (with anomalies) and `init` (smooth), both (nz, nx) float32, plus padded versions."""
     rng = np.random.default_rng(seed)
@@ -55,7 +55,11 @@ def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, 
     if das_fiber == "vertical":   # a borehole fibre: one column, consecutive depths
         rec_zs = np.arange(4, nz - 4, nrec_stride).astype(int)
         rec_x = np.full(rec_zs.shape, nx // 2 + 3, dtype=int)
-    ft.surveyGen(src_zs, src_x, rec_zs, rec_x, survey_fname)
+    if das_sensitivity == "random":   # a shaped fibre: every channel its own direction cosines (seeded)
+        th = np.random.default_rng(seed + 99).uniform(0.0, np.pi, rec_x.size)
+        das_sensitivity = np.zeros((rec_x.size, 6))
+        das_sensitivity[:, 0], das_sensitivity[:, 3], das_sensitivity[:, 1] = np.cos(th) ** 2, np.sin(th) ** 2, 2.0 * np.sin(th) * np.cos(th)
+    ft.surveyGen(src_zs, src_x, rec_zs, rec_x, survey_fname, Das_sensitivity=das_sensitivity)
     stf = ft.sourceGene(f0, nSteps, dt) if stf is None else np.asarray(stf)
     Stf = torch.tensor(stf, dtype=torch.float32).repeat(nshots, 1)
     Shot_ids = torch.arange(nshots, dtype=torch.int32)

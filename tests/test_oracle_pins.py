@@ -153,3 +153,81 @@ def test_long_run_golden_is_what_the_oracle_computes(tmp_path, oracle):
     for k in ("gLambda", "gMu", "gDen"):
         assert np.array_equal(ref[k][n:n + nz, n:n + nx + 1], G[k]), k
     assert np.array_equal(ref["gStf"][0], G["gStf"])
+
+
+def test_directional_das_reduces_to_the_straight_fibres(oracle, tmp_path):
+    """Survey key "das_sensitivity" (SURVEY.md 8f-3): with weight 1 on exx alone the directional channel IS recording_exx,
+    with weight 1 on ezz alone it IS recording_ezz (Src/utilities.cu:593-602,620-629), observed data and gradients, bit
+    for bit."""
+    import problems as P
+    for col, fiber in ((0, "horizontal"), (3, "vertical")):
+        pb0 = P.make_problem(str(tmp_path / ("f" + fiber)), hetero=True, nSteps=150, das_fiber=fiber, nshots=1)
+        nrec = pb0["nrec"]
+        sens = np.zeros((nrec, 6)); sens[:, col] = 1.0
+        sv = {k: (dict(v, das_sensitivity=sens.tolist()) if k.startswith("shot") and k != "nShots" and isinstance(v, dict) else v)
+              for k, v in pb0["survey"].items()}
+        para_h = dict(pb0["para"]); para_h.pop("das_fiber", None)
+        lam_t, mu_t, den_t = [t.numpy() for t in pb0["lame_true"]]
+        lam, mu, den = [t.numpy() for t in pb0["lame_init"]]
+        stf, ids = pb0["Stf"].numpy(), pb0["Shot_ids"].numpy()
+        obs0 = oracle.cufd(lam_t, mu_t, den_t, stf, 2, ids, pb0["para"], pb0["survey"])["syn"]
+        obs1 = oracle.cufd(lam_t, mu_t, den_t, stf, 2, ids, para_h, sv)["syn"]
+        assert np.array_equal(obs0, obs1), fiber
+        g0 = oracle.cufd(lam, mu, den, stf, 1, ids, pb0["para"], pb0["survey"], obs=obs0)
+        g1 = oracle.cufd(lam, mu, den, stf, 1, ids, para_h, sv, obs=obs1)
+        for k in ("misfit", "gLambda", "gMu", "gDen", "gStf"):
+            assert np.array_equal(g0[k], g1[k]), (fiber, k)
+
+
+def test_directional_das_matches_the_numba_solver(oracle, tmp_path):
+    """ett = s0 exx + s3 ezz + s1 exz (MOD/elasticSolver.py:266-276).  The Numba oracle is bit-exact to the reference's
+    Python solver (golden ett traces, test_numba_oracle_bit_exact_small); here the CUDA-path oracle's directional channel,
+    with random per-channel sensitivities, agrees with it on a homogeneous medium before the absorbers differ -- same
+    comparison, factor 1500^2 1e7 dt / (dt/2) and strain x dx, as for the plain exx channel above."""
+    n, npml, nt, dh, dt, f0 = 80, 20, 200, 10.0, 1.0e-3, 25.0
+    rng = np.random.default_rng(5)
+    pb = P.make_problem(str(tmp_path), nz=n, nx=n, nPml=npml, nSteps=nt, nshots=1, dh=dh, dt=dt, f0=f0, hetero=False,
+                        src_z=40, src_x=[40], rec_z=30)
+    nrec = pb["nrec"]
+    sens = np.zeros((nrec, 6))
+    sens[:, 0], sens[:, 3], sens[:, 1] = rng.uniform(-1, 1, nrec), rng.uniform(-1, 1, nrec), rng.uniform(-1, 1, nrec)
+    sens[:, [2, 4, 5]] = rng.uniform(-1, 1, (nrec, 3))          # columns the 2-D solver ignores
+    sv = dict(pb["survey"]); sv["shot0"] = dict(sv["shot0"], das_sensitivity=sens.tolist())
+    lam, mu, den = pb["lame_init"]
+    syn = oracle.cufd(lam.numpy(), mu.numpy(), den.numpy(), pb["Stf"].numpy(), 2, [0], pb["para"], sv)["syn"][0]
+    s0 = sv["shot0"]
+    vp = np.full((n, n), 3000.0)
+    rec = np.stack([np.asarray(s0["x_rec"]) * dh, np.asarray(s0["z_rec"]) * dh], 1).astype(float)
+    src = np.array([[s0["x_src"] * dh, s0["z_src"] * dh]], float)
+    nb = oracle.numba_forward(n, n, npml, dh, dh, dt, nt, f0, vp, vp / 1.732, np.full((n, n), 2400.0), src, rec, rec, sens)[0]
+    fac = 1500.0 ** 2 * 1.0e7 * dt / (dt / 2.0)
+    early = 150
+    sel = np.where(np.abs(np.asarray(s0["x_rec"]) - s0["x_src"]) < 14)[0]
+    ref = nb["ett"] * dh * fac
+    e = P.rel_l2(syn[3][sel, :early], ref[sel, :early])
+    assert e <= 2e-3, e
+    # each strain component on its own (sensitivity 1 on one column) -- catches a swapped column or staggering
+    for col, key in ((0, "exx"), (3, "ezz"), (1, "exz")):
+        one = np.zeros((nrec, 6)); one[:, col] = 1.0
+        sv1 = dict(pb["survey"]); sv1["shot0"] = dict(sv["shot0"], das_sensitivity=one.tolist())
+        s1 = oracle.cufd(lam.numpy(), mu.numpy(), den.numpy(), pb["Stf"].numpy(), 2, [0], pb["para"], sv1)["syn"][0]
+        e = P.rel_l2(s1[3][sel, :early], nb[key][sel, :early] * dh * fac)
+        assert e <= 3e-3, (key, e)
+        assert P.rel_l2(s1[3][sel, 1:early + 1], nb[key][sel, :early] * dh * fac) > 10 * max(e, 1e-4), key
+
+
+def test_directional_das_gradient_is_consistent_with_finite_differences(oracle, tmp_path):
+    """The directional adjoint source is the transpose of the directional recording: <g, d> follows the misfit's
+    directional derivative as closely as the reference's own exx channel does (homogeneous background)."""
+    pb = P.make_problem(str(tmp_path), hetero=False, nSteps=220, nshots=1, src_x=[20], das_sensitivity="random")
+    lam_t, mu_t, den_t = [t.numpy() for t in pb["lame_true"]]
+    lam, mu, den = [t.numpy() for t in pb["lame_init"]]
+    stf, ids = pb["Stf"].numpy(), pb["Shot_ids"].numpy()
+    obs = oracle.cufd(lam_t, mu_t, den_t, stf, 2, ids, pb["para"], pb["survey"])["syn"]
+    r0 = oracle.cufd(lam, mu, den, stf, 1, ids, pb["para"], pb["survey"], obs=obs)
+    d = r0["gDen"] / np.abs(r0["gDen"]).max()
+    eps = 2.0
+    fp = oracle.cufd(lam, mu, den + eps * d, stf, 0, ids, pb["para"], pb["survey"], obs=obs)["misfit"]
+    fm = oracle.cufd(lam, mu, den - eps * d, stf, 0, ids, pb["para"], pb["survey"], obs=obs)["misfit"]
+    fd, gd = (fp - fm) / (2 * eps), float((r0["gDen"] * d).sum())
+    assert abs(fd - gd) <= 0.05 * abs(gd), (fd, gd)
