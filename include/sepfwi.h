@@ -142,6 +142,25 @@ int sepfwi_set_option(const char *name, int value);
 int sepfwi_get_option(const char *name);
 
 /*
+ * Fused parameterisation maps for HIP-resident tensors: what the reference's nn.Modules compute with a
+ * dozen elementwise torch kernels per iteration on the CPU -- replicate padding (fwi_utils.py:31-44 with the identity
+ * resize), mask blend P_m = Mask P_pad + (1 - Mask) P_ref (FWI_ops.py:120-122), the Lame map -- in ONE launch, and the
+ * whole chain rule back to the (nz, nx) parameters (Lame derivatives, mask, transpose of the padding) in ONE.
+ *   kind: 0 (Vp, Vs, Den) FWI_ops.py:124-125 | 1 (Lambda, Mu, Den) :204 | 2 (IP, IS, Den) :261-262 |
+ *         3 (Vp, Vs, IP) :326-328 | 4 (Vp, Vs, IS) :389-391
+ *   A, B, C            (nz, nx) physical grid;  *_ref, Mask, Lambda, Mu, Den, gLambda, gMu, gDen:
+ *                      (nz + 2 nPml + nPad, nx + 2 nPml) padded grid; gA, gB, gC: (nz, nx).  All float32 row-major DEVICE
+ *                      pointers of one device; launched on hip_stream (NULL: the default stream), not synchronised.
+ */
+int sepfwi_param_forward(int kind, int nz, int nx, int nPml, int nPad, const float *A, const float *B, const float *C,
+                         const float *A_ref, const float *B_ref, const float *C_ref, const float *Mask, float *Lambda,
+                         float *Mu, float *Den, void *hip_stream);
+int sepfwi_param_backward(int kind, int nz, int nx, int nPml, int nPad, const float *A, const float *B, const float *C,
+                          const float *A_ref, const float *B_ref, const float *C_ref, const float *Mask,
+                          const float *gLambda, const float *gMu, const float *gDen, float *gA, float *gB, float *gC,
+                          void *hip_stream);
+
+/*
  * Test hook: wavefield `which` (0..4: vz, vx, szz, sxx, sxz; 5..9: their adjoint twins) of forward lane `lane` as the last
  * sepfwi_cufd* call on (para_fname, gpu_id) left it, dense (nz - nPad, nx) row-major float32, host or device pointer.
  * After a gradient call the forward fields are the reverse-time RECONSTRUCTION run back to time step 0, i.e. they must

@@ -2,9 +2,11 @@
 // failure becomes an error code plus a thread-local message (the reference printf()s and exit(1)s,
 // Src/utilities.h:28-36, which would take the Python interpreter down).
 #include <cstring>
+#include <initializer_list>
 #include <string>
 
 #include "kernels.hpp"
+#include "param_maps.hpp"
 #include "session.hpp"
 
 using namespace sepfwi;
@@ -130,6 +132,51 @@ int sepfwi_debug_field(const char *para_fname, int gpu_id, int lane, int which, 
         std::shared_ptr<Session> s = find_session(para_fname, gpu_id);
         if (!s) throw std::invalid_argument("no session for this parameter file / gpu");
         s->copy_field(lane, which, out);
+    });
+}
+
+// every pointer of the fused parameterisation maps must be device memory of ONE device (the maps run where the tensors live)
+static int common_device(std::initializer_list<const void *> ptrs) {
+    int dev = -1;
+    for (const void *p : ptrs) {
+        hipPointerAttribute_t attr;
+        if (!p || hipPointerGetAttributes(&attr, p) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
+            (void)hipGetLastError();
+            throw std::invalid_argument("param maps: every array must be device memory (the host chain stays in torch)");
+        }
+        if (dev >= 0 && attr.device != dev) throw std::invalid_argument("param maps: arrays live on different devices");
+        dev = attr.device;
+    }
+    return dev;
+}
+
+static void check_param_dims(int kind, int nz, int nx, int nPml, int nPad) {
+    if (kind < 0 || kind >= PARAM_KINDS) throw std::invalid_argument("param maps: unknown parameterisation " + std::to_string(kind));
+    if (nz < 1 || nx < 1 || nPml < 0 || nPad < 0) throw std::invalid_argument("param maps: bad sizes");
+}
+
+int sepfwi_param_forward(int kind, int nz, int nx, int nPml, int nPad, const float *A, const float *B, const float *C,
+                         const float *A_ref, const float *B_ref, const float *C_ref, const float *Mask, float *Lambda, float *Mu,
+                         float *Den, void *hip_stream) {
+    return guarded([&] {
+        check_param_dims(kind, nz, nx, nPml, nPad);
+        const int dev = common_device({A, B, C, A_ref, B_ref, C_ref, Mask, Lambda, Mu, Den});
+        if (hipSetDevice(dev) != hipSuccess) throw HipError("hipSetDevice failed");
+        launch_param_fwd((hipStream_t)hip_stream, kind, nz, nx, nPml, nPad, A, B, C, A_ref, B_ref, C_ref, Mask, Lambda, Mu, Den);
+        if (hipGetLastError() != hipSuccess) throw HipError("param map launch failed");
+    });
+}
+
+int sepfwi_param_backward(int kind, int nz, int nx, int nPml, int nPad, const float *A, const float *B, const float *C,
+                          const float *A_ref, const float *B_ref, const float *C_ref, const float *Mask, const float *gLambda,
+                          const float *gMu, const float *gDen, float *gA, float *gB, float *gC, void *hip_stream) {
+    return guarded([&] {
+        check_param_dims(kind, nz, nx, nPml, nPad);
+        const int dev = common_device({A, B, C, A_ref, B_ref, C_ref, Mask, gLambda, gMu, gDen, gA, gB, gC});
+        if (hipSetDevice(dev) != hipSuccess) throw HipError("hipSetDevice failed");
+        launch_param_bwd((hipStream_t)hip_stream, kind, nz, nx, nPml, nPad, A, B, C, A_ref, B_ref, C_ref, Mask, gLambda, gMu, gDen, gA,
+                         gB, gC);
+        if (hipGetLastError() != hipSuccess) throw HipError("param map launch failed");
     });
 }
 

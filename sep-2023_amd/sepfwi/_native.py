@@ -12,8 +12,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
-SOURCES = ["kernels.hip", "session.cpp", "config.cpp", "capi.cpp"]
-HEADERS = ["kernels.hpp", "device_common.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+SOURCES = ["kernels.hip", "param_maps.hip", "session.cpp", "config.cpp", "capi.cpp"]
+HEADERS = ["kernels.hpp", "param_maps.hpp", "device_common.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
 _lib = None
@@ -71,11 +71,13 @@ def lib():
     L.sepfwi_get_stats.argtypes = [C.c_char_p, C.c_int, C.POINTER(Stats)]
     L.sepfwi_set_option.argtypes = [C.c_char_p, C.c_int]
     L.sepfwi_get_option.argtypes = [C.c_char_p]
+    L.sepfwi_param_forward.argtypes = [C.c_int] * 5 + [fp] * 10 + [C.c_void_p]
+    L.sepfwi_param_backward.argtypes = [C.c_int] * 5 + [fp] * 13 + [C.c_void_p]
     L.sepfwi_debug_field.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, fp]
     L.sepfwi_set_observed.argtypes = [C.c_char_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
     for f in ("sepfwi_cufd", "sepfwi_cufd_stream", "sepfwi_cpml_profiles", "sepfwi_stf_taper", "sepfwi_shot_split",
               "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_get_option", "sepfwi_debug_field", "sepfwi_set_observed",
-              "sepfwi_version", "sepfwi_device_count"):
+              "sepfwi_param_forward", "sepfwi_param_backward", "sepfwi_version", "sepfwi_device_count"):
         getattr(L, f).restype = C.c_int
     L.sepfwi_release_all.restype = None
     L.sepfwi_invalidate_observed.restype = None
@@ -86,7 +88,7 @@ def lib():
 EXPORTS = ["sepfwi_last_error", "sepfwi_version", "sepfwi_device_count", "sepfwi_cufd", "sepfwi_cufd_stream",
            "sepfwi_release_all", "sepfwi_invalidate_observed", "sepfwi_cpml_profiles", "sepfwi_stf_taper",
            "sepfwi_shot_split", "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_get_option", "sepfwi_debug_field",
-           "sepfwi_set_observed"]
+           "sepfwi_set_observed", "sepfwi_param_forward", "sepfwi_param_backward"]
 
 
 class SepFwiError(RuntimeError):

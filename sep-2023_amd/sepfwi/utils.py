@@ -106,3 +106,38 @@ def sourceGene(f, nStep, delta_t):
 def read_shot_gather(data_dir, comp, shot_id, nSteps):
     """Shot_{pr|vx|vz|ett}{id}.bin -> (nrec, nSteps) float32 (libCUFD.cu:755-769)."""
     return np.fromfile(os.path.join(data_dir, "Shot_%s%d.bin" % (comp, shot_id)), dtype=np.float32).reshape(-1, nSteps)
+
+
+# Mineral / fluid constants of the reference's rock-physics maps (fwi_utils.py:156-167,311-322; FWI_ops.py:452-462,573-584):
+# quartz, clay, water, hydrocarbon; cs = consolidation parameter of the drained frame (Dupuy et al. 2016).
+ROCK = dict(k_q=37.00 * 1e9, k_c=21.00 * 1e9, k_w=2.25 * 1e9, k_h=0.04 * 1e9, mu_q=44.00 * 1e9, mu_c=10.00 * 1e9,
+            rho_q=2.65 * 1e3, rho_c=2.55 * 1e3, rho_w=1.00 * 1e3, rho_h=0.10 * 1e3, cs=20.0)
+
+
+def pcs2dv_vrh(phi, cc, sw):
+    """(porosity, clay content, water saturation) -> (vp, vs, rho), Voigt-Reuss-Hill   (fwi_utils.py:154-196)."""
+    R = ROCK
+    kv = (1 - phi) * (R["k_c"] * cc + R["k_q"] * (1 - cc)) + phi * (R["k_w"] * sw + R["k_h"] * (1 - sw))
+    kr_1 = (1 - phi) * (cc / R["k_c"] + (1 - cc) / R["k_q"]) + phi * (sw / R["k_w"] + (1 - sw) / R["k_h"])
+    k = 0.5 * (kv + 1 / kr_1)
+    mu = 0.5 * ((1 - phi) * (R["mu_c"] * cc + R["mu_q"] * (1 - cc)) + 0)
+    rho = (R["rho_w"] * sw + R["rho_h"] * (1 - sw)) * phi + (R["rho_c"] * cc + R["rho_q"] * (1 - cc)) * (1 - phi)
+    lam = k - 2. / 3. * mu
+    return np.sqrt((lam + 2. * mu) / rho), np.sqrt(mu / rho), rho
+
+
+def pcs2dv_gassmann(phi, cc, sw):
+    """(porosity, clay content, water saturation) -> (vp, vs, rho), Biot-Gassmann with Voigt mineral mixing
+    (fwi_utils.py:309-352: weighted_average, vrh(method='Voigt'), drained_moduli, biot_gassmann)."""
+    R = ROCK
+    rho_f = R["rho_w"] * sw + R["rho_h"] * (1 - sw)
+    k_f = R["k_w"] * sw + R["k_h"] * (1 - sw)
+    k_s = R["k_c"] * cc + R["k_q"] * (1 - cc)
+    mu_s = R["mu_c"] * cc + R["mu_q"] * (1 - cc)
+    rho_s = R["rho_c"] * cc + R["rho_q"] * (1 - cc)
+    k_d = k_s * ((1 - phi) / (1 + R["cs"] * phi))
+    mu_d = mu_s * ((1 - phi) / (1 + 1.5 * R["cs"] * phi))
+    delta = ((1 - phi) / phi) * (k_f / k_s) * (1 - (k_d / (k_s - k_s * phi)))
+    k_u = (phi * k_d + (1 - (1 + phi) * (k_d / k_s)) * k_f) / (phi * (1 + delta))
+    rho = rho_f * phi + rho_s * (1 - phi)
+    return np.sqrt((k_u + 0.75 * mu_d) / rho), np.sqrt(mu_d / rho), rho

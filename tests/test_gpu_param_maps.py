@@ -1,0 +1,112 @@
+"""Fused parameterisation maps (csrc/param_maps.hip) on the GPU against the torch expressions of the
+reference's modules (FWI_ops.py:116-127,194-204,256-266,319-330,381-393) evaluated on the CPU: forward maps bit for bit
+(same float32 operation order, no contraction), chain rule to rounding (the padding transpose sums in another order)."""
+import numpy as np
+import pytest
+import torch
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = ["FWI", "FWI_Lame_Den", "FWI_IP_IS_Den", "FWI_Vp_Vs_IP", "FWI_Vp_Vs_IS"]
+
+
+def _fields(cls_name, pb):
+    vp, vs, rho = [pb["true"][k].astype(np.float64) for k in ("vp", "vs", "rho")]
+    if cls_name == "FWI":
+        return vp, vs, rho
+    if cls_name == "FWI_Lame_Den":
+        return rho * (vp ** 2 - 2 * vs ** 2) / 1e6, rho * vs ** 2 / 1e6, rho
+    if cls_name == "FWI_IP_IS_Den":
+        return vp / 1e3 * rho, vs / 1e3 * rho, rho
+    if cls_name == "FWI_Vp_Vs_IP":
+        return vp, vs, rho * vp
+    return vp, vs, rho * vs
+
+
+@pytest.mark.parametrize("cls_name", CLASSES)
+def test_fused_maps_equal_torch_expressions(tmp_path, hip_ops, cls_name):
+    from sepfwi import modules as M
+    pb = P.make_problem(str(tmp_path), nz=37, nx=70, nPml=9, nSteps=10, nshots=1, nPad=5)
+    rng = np.random.default_rng(3)
+    mask = (rng.uniform(size=(pb["nz_pad"], pb["nx_pad"])) > 0.3).astype(np.float32)
+    mask[20:30, 15:40] = rng.uniform(0.1, 0.9, (10, 25))          # fractional blending too
+    mask[:, :5] = 1.0; mask[-7:, :] = 1.0                          # padding strips that DO depend on the edge cells
+    gl, gm, gd = [torch.tensor(rng.standard_normal((pb["nz_pad"], pb["nx_pad"])).astype(np.float32)) for _ in range(3)]
+    outs = {}
+    for dev in ("cpu", "cuda"):
+        f = [torch.tensor(a.astype(np.float32), device=dev, requires_grad=True) for a in _fields(cls_name, pb)]
+        # the reference model differs from the current one (as after some iterations)
+        ref = [torch.tensor((a * 1.03).astype(np.float32), device=dev) for a in _fields(cls_name, pb)]
+        mod = getattr(M, cls_name)(ref[0], ref[1], ref[2], pb["Stf"], pb["opt"], Mask=torch.tensor(mask, device=dev))
+        for n, t in zip(mod.NAMES, f):
+            setattr(mod, n, torch.nn.Parameter(t))
+        assert mod._fusable() == (dev == "cuda")
+        lam, mu, den = mod.lame_padded()
+        (lam * gl.to(dev)).sum().add((mu * gm.to(dev)).sum()).add((den * gd.to(dev)).sum()).backward()
+        outs[dev] = [t.detach().cpu().numpy() for t in (lam, mu, den)] + [getattr(mod, n).grad.cpu().numpy() for n in mod.NAMES]
+    for k in range(3):
+        assert np.array_equal(outs["cuda"][k], outs["cpu"][k]), (cls_name, "forward", k)
+    for k in range(3, 6):
+        scale = np.abs(outs["cpu"][k]).max()
+        assert np.abs(outs["cuda"][k] - outs["cpu"][k]).max() <= 2e-6 * scale, (cls_name, "backward", k)
+
+
+def test_fused_and_torch_chains_give_the_same_fwi_gradient(tmp_path, oracle, hip_ops):
+    """The whole device-resident iteration (module -> FWIFunction -> HIP propagator -> chain rule) with the fused maps and
+    with the torch expressions on the GPU."""
+    from sepfwi import modules as M
+    pb = P.make_problem(str(tmp_path), hetero=True, nSteps=150, nshots=2)
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    mask = torch.zeros(pb["nz_pad"], pb["nx_pad"]); mask[pb["nPml"] + 3:pb["nPml"] + 44, pb["nPml"]:pb["nPml"] + 60] = 1.0
+    res = {}
+    for fused in (True, False):
+        M.USE_FUSED_MAPS = fused
+        try:
+            f = [torch.tensor(pb["init"][k], device="cuda", requires_grad=True) for k in ("vp", "vs", "rho")]
+            fwi = M.FWI(f[0], f[1], f[2], pb["Stf"], pb["opt"], Mask=mask.cuda())
+            loss = fwi(pb["Shot_ids"], ngpu=1)
+            loss.backward()
+            res[fused] = [float(loss)] + [p.grad.cpu().numpy() for p in fwi.parameters()]
+        finally:
+            M.USE_FUSED_MAPS = True
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+
+
+def test_fused_maps_at_headline_size_and_timing(hip_ops):
+    """2000 x 1000: one launch each way instead of the torch chain; prints both times."""
+    import time
+    from sepfwi import modules as M
+    from sepfwi import utils as ft
+    nz, nx, nPml = 1000, 2000, 32
+    nPad = ft.nPad_for(nz, nPml)
+    opt = dict(nz=nz, nx=nx, nz_orig=nz, nx_orig=nx, nPml=nPml, nPad=nPad, para_fname="unused.json")
+    g = torch.Generator().manual_seed(0)
+    vp = (3000.0 + 500.0 * torch.rand(nz, nx, generator=g)).cuda()
+    vs, rho = (vp / 1.8).contiguous(), (2000.0 + 0.2 * vp).contiguous()
+    times = {}
+    grads = {}
+    for fused in (True, False):
+        M.USE_FUSED_MAPS = fused
+        try:
+            f = [t.clone().requires_grad_(True) for t in (vp, vs, rho)]
+            fwi = M.FWI(f[0], f[1], f[2], None, opt)
+            for rep in range(3):
+                for p in fwi.parameters():
+                    p.grad = None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lam, mu, den = fwi.lame_padded()
+                (lam.sum() + 2.0 * mu.sum() + den.sum()).backward()
+                torch.cuda.synchronize()
+                times[fused] = time.perf_counter() - t0
+            grads[fused] = [p.grad.clone() for p in fwi.parameters()]
+        finally:
+            M.USE_FUSED_MAPS = True
+    print("pad + mask + Lame map + chain rule at 2000x1000: fused %.2f ms, torch ops %.2f ms" % (1e3 * times[True], 1e3 * times[False]))
+    for a, b in zip(grads[True], grads[False]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())

@@ -216,3 +216,75 @@ def test_bench_launcher_command_line():
     assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     free = bench.launcher_cmd(2, [])
     assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+
+
+def _module_case(tmp_path, cls_name, fields, monkeypatch):
+    import sepfwi.ops as ops
+    from sepfwi import modules as M
+    fake = _FakeOps()
+    monkeypatch.setattr(ops, "fwi_ops", fake)
+    pb = P.make_problem(str(tmp_path), nz=12, nx=14, nPml=4, nSteps=10, nshots=1, nPad=3)
+    params = [torch.tensor(np.ascontiguousarray(f, dtype=np.float32), requires_grad=True) for f in fields]
+    mask = torch.zeros(pb["nz_pad"], pb["nx_pad"]); mask[4:16, 4:18] = 1.0
+    fwi = getattr(M, cls_name)(params[0], params[1], params[2], pb["Stf"], pb["opt"], Mask=mask)
+    loss = fwi(pb["Shot_ids"], ngpu=1)
+    loss.backward()
+    lam, mu, den = [t[4:16, 4:18].numpy().astype(np.float64) for t in fake.calls[0][:3]]
+    return pb, fwi, lam, mu, den
+
+
+def test_impedance_velocity_modules(monkeypatch, tmp_path):
+    """FWI_Vp_Vs_IP / FWI_Vp_Vs_IS (FWI_ops.py:270-393): Lame map and chain rule with gLambda = 2, gMu = -1, gDen = 0.5
+    (_FakeOps) against the formulas written out by hand."""
+    pb = P.make_problem(str(tmp_path / "m"), nz=12, nx=14, nPml=4, nSteps=10, nshots=1, nPad=3)
+    vp, vs, rho = [pb["init"][k].astype(np.float64) for k in ("vp", "vs", "rho")]
+    gl, gm, gd = 2.0, -1.0, 0.5
+    ip = rho * vp
+    _, fwi, lam, mu, den = _module_case(tmp_path / "ip", "FWI_Vp_Vs_IP", (vp, vs, ip), monkeypatch)
+    assert [n for n, _ in fwi.named_parameters()] == ["Vp", "Vs", "IP"]
+    np.testing.assert_allclose(den, rho, rtol=1e-6)
+    np.testing.assert_allclose(mu, rho * vs ** 2, rtol=1e-6)
+    np.testing.assert_allclose(lam, rho * (vp ** 2 - 2 * vs ** 2), rtol=1e-5)
+    np.testing.assert_allclose(fwi.IP.grad.numpy(), gl * (vp - 2 * vs ** 2 / vp) + gm * vs ** 2 / vp + gd / vp, rtol=1e-5)
+    np.testing.assert_allclose(fwi.Vs.grad.numpy(), gl * (-4 * ip * vs / vp) + gm * 2 * ip * vs / vp, rtol=1e-5)
+    np.testing.assert_allclose(fwi.Vp.grad.numpy(), gl * (ip + 2 * ip * vs ** 2 / vp ** 2) - gm * ip * vs ** 2 / vp ** 2 - gd * ip / vp ** 2, rtol=1e-5)
+    is_ = rho * vs
+    _, fwi, lam, mu, den = _module_case(tmp_path / "is", "FWI_Vp_Vs_IS", (vp, vs, is_), monkeypatch)
+    assert [n for n, _ in fwi.named_parameters()] == ["Vp", "Vs", "IS"]
+    np.testing.assert_allclose(den, rho, rtol=1e-6)
+    np.testing.assert_allclose(mu, rho * vs ** 2, rtol=1e-6)
+    np.testing.assert_allclose(lam, rho * (vp ** 2 - 2 * vs ** 2), rtol=1e-5)
+    np.testing.assert_allclose(fwi.IS.grad.numpy(), gl * (vp ** 2 / vs - 2 * vs) + gm * vs + gd / vs, rtol=1e-5)
+    np.testing.assert_allclose(fwi.Vp.grad.numpy(), gl * 2 * is_ * vp / vs, rtol=1e-5)
+    np.testing.assert_allclose(fwi.Vs.grad.numpy(), gl * (-is_ * vp ** 2 / vs ** 2 - 2 * is_) + gm * is_ - gd * is_ / vs ** 2, rtol=1e-5)
+
+
+def test_rock_physics_maps_match_reference_vectors(monkeypatch, tmp_path):
+    """FWI_Rock_Physics_VRH / _gassmann (FWI_ops.py:401-619) and utils.pcs2dv_* against golden vectors produced by importing
+    the reference's own fwi_utils.py (scripts/make_golden_rockphysics.py): (phi, cc, sw) -> vp, vs, rho."""
+    from conftest import GOLDEN
+    from sepfwi import utils as ft
+    G = np.load(os.path.join(GOLDEN, "rock_physics.npz"))
+    phi, cc, sw = G["phi"], G["cc"], G["sw"]
+    for name, fn in (("vrh", ft.pcs2dv_vrh), ("gas", ft.pcs2dv_gassmann)):
+        vp, vs, rho = fn(phi, cc, sw)
+        for got, key in ((vp, "vp"), (vs, "vs"), (rho, "rho")):
+            np.testing.assert_allclose(got, G["%s_%s" % (name, key)], rtol=1e-13)
+    # the modules' Lame maps give the same media: lambda = rho (vp^2 - 2 vs^2), mu = rho vs^2 [MPa]
+    from sepfwi import modules as M
+    pb = P.make_problem(str(tmp_path), nz=12, nx=17, nPml=4, nSteps=10, nshots=1, nPad=3)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    for cls, name in ((M.FWI_Rock_Physics_VRH, "vrh"), (M.FWI_Rock_Physics_gassmann, "gas")):
+        lam, mu, den = cls.lame(None, T(phi), T(cc), T(sw))
+        vp, vs, rho = G[name + "_vp"], G[name + "_vs"], G[name + "_rho"]
+        np.testing.assert_allclose(den.numpy(), rho, rtol=1e-12)
+        np.testing.assert_allclose(mu.numpy(), rho * vs ** 2 / 1e6, rtol=1e-10)
+        np.testing.assert_allclose(lam.numpy(), rho * (vp ** 2 - 2 * vs ** 2) / 1e6, rtol=1e-9)
+    # and they are differentiable modules with the reference's parameter names
+    import sepfwi.ops as ops
+    monkeypatch.setattr(ops, "fwi_ops", _FakeOps())
+    P32 = lambda a: torch.tensor(a.astype(np.float32), requires_grad=True)
+    fwi = M.FWI_Rock_Physics_gassmann(P32(phi), P32(cc), P32(sw), pb["Stf"], pb["opt"])
+    fwi(pb["Shot_ids"], ngpu=1).backward()
+    assert [n for n, _ in fwi.named_parameters()] == ["PHI", "CC", "SW"]
+    assert all(torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in fwi.parameters())
