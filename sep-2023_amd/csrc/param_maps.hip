@@ -1,6 +1,7 @@
 // param_maps.hip -- the parameterisation maps of the callers of the operator boundary, fused: user parameters on the
 // physical (nz, nx) grid -> replicate padding -> mask blend with the reference model -> (Lambda [MPa], Mu [MPa], Den) on the
-// padded grid in ONE launch, and the whole chain rule back (Lame derivatives, mask, transpose of the padding) in ONE.
+// padded grid in ONE launch, and the whole chain rule back (Lame derivatives, mask, transpose of the padding) in one
+// launch over the grid plus a small one over its rim.
 //
 // Replaces, for HIP-resident tensors, the ~20 elementwise torch kernels over 3 x 9 MB that the reference's modules issue per
 // iteration on the CPU (DAS_Waveform_Inversion/Ops/FWI/FWI_ops.py:116-127 FWI, :194-204 FWI_Lame_Den, :256-266 FWI_IP_IS_Den,
@@ -115,8 +116,7 @@ __global__ void k_param_fwd(int kind, int nz, int nx, int nPml, int nzp, int nxp
     Den[o] = r.c;
 }
 
-// one thread per PHYSICAL cell: gathers every padded cell that replicates it (its own; for edge cells the strip of the
-// padding it feeds; for the four corner cells a rectangle), rows outer, columns inner
+// one thread per PHYSICAL cell: the padded cell that is the cell itself
 __global__ void k_param_bwd(int kind, int nz, int nx, int nPml, int nzp, int nxp, const float *__restrict__ A,
                             const float *__restrict__ B, const float *__restrict__ C, const float *__restrict__ A_ref,
                             const float *__restrict__ B_ref, const float *__restrict__ C_ref, const float *__restrict__ Mask,
@@ -124,25 +124,60 @@ __global__ void k_param_bwd(int kind, int nz, int nx, int nPml, int nzp, int nxp
                             float *__restrict__ gA, float *__restrict__ gB, float *__restrict__ gC) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= nx || z >= nz) return;
+    const size_t s = (size_t)z * nx + x, o = (size_t)(z + nPml) * nxp + (x + nPml);
+    const float m = Mask[o], w = 1.0f - m;
+    const Triple d = map_bwd(kind, m * A[s] + w * A_ref[o], m * B[s] + w * B_ref[o], m * C[s] + w * C_ref[o], gLam[o], gMu[o], gDen[o]);
+    gA[s] = m * d.a;
+    gB[s] = m * d.b;
+    gC[s] = m * d.c;
+}
+
+// Transpose of the replicate padding: one WAVE per cell of the physical grid's rim adds the padded cells that replicate
+// it (a strip of the padding for an edge cell, a rectangle for the four corners; its own cell is done above).  Lanes
+// stride over the cells row-major, then a shuffle tree: a fixed summation order, no atomics.
+__global__ void k_param_bwd_rim(int kind, int nz, int nx, int nPml, int nzp, int nxp, const float *__restrict__ A,
+                                const float *__restrict__ B, const float *__restrict__ C, const float *__restrict__ A_ref,
+                                const float *__restrict__ B_ref, const float *__restrict__ C_ref, const float *__restrict__ Mask,
+                                const float *__restrict__ gLam, const float *__restrict__ gMu, const float *__restrict__ gDen,
+                                float *__restrict__ gA, float *__restrict__ gB, float *__restrict__ gC) {
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // rim cell: top row, bottom row, then the two columns
+    int z, x;
+    if (r < nx) { z = 0; x = r; }
+    else if (r < 2 * nx) { z = nz - 1; x = r - nx; }
+    else if (r < 2 * nx + (nz - 2)) { z = r - 2 * nx + 1; x = 0; }
+    else if (r < 2 * nx + 2 * (nz - 2)) { z = r - 2 * nx - (nz - 2) + 1; x = nx - 1; }
+    else return;
+    if (nz == 1 && r >= nx) return;  // a one-row grid has one rim row
+    if (nx == 1 && r >= 2 * nx && r >= 2 * nx + (nz - 2)) return;
     const size_t s = (size_t)z * nx + x;
     const int Z0 = (z == 0) ? 0 : z + nPml, Z1 = (z == nz - 1) ? nzp - 1 : z + nPml;
     const int X0 = (x == 0) ? 0 : x + nPml, X1 = (x == nx - 1) ? nxp - 1 : x + nPml;
+    const int w_ = X1 - X0 + 1, cnt = (Z1 - Z0 + 1) * w_;
     const float a0 = A[s], b0 = B[s], c0 = C[s];
     float ga = 0.0f, gb = 0.0f, gc = 0.0f;
-    for (int Z = Z0; Z <= Z1; Z++)
-        for (int X = X0; X <= X1; X++) {
-            const size_t o = (size_t)Z * nxp + X;
-            const float m = Mask[o];
-            if (m == 0.0f) continue;  // the cell does not depend on the parameters at all
-            const float w = 1.0f - m;
-            const Triple d = map_bwd(kind, m * a0 + w * A_ref[o], m * b0 + w * B_ref[o], m * c0 + w * C_ref[o], gLam[o], gMu[o], gDen[o]);
-            ga += m * d.a;
-            gb += m * d.b;
-            gc += m * d.c;
-        }
-    gA[s] = ga;
-    gB[s] = gb;
-    gC[s] = gc;
+    for (int k = lane; k < cnt; k += 64) {
+        const int Z = Z0 + k / w_, X = X0 + k % w_;
+        if (Z == z + nPml && X == x + nPml) continue;  // the cell itself
+        const size_t o = (size_t)Z * nxp + X;
+        const float m = Mask[o];
+        if (m == 0.0f) continue;
+        const float w = 1.0f - m;
+        const Triple d = map_bwd(kind, m * a0 + w * A_ref[o], m * b0 + w * B_ref[o], m * c0 + w * C_ref[o], gLam[o], gMu[o], gDen[o]);
+        ga += m * d.a;
+        gb += m * d.b;
+        gc += m * d.c;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ga += __shfl_down(ga, off, 64);
+        gb += __shfl_down(gb, off, 64);
+        gc += __shfl_down(gc, off, 64);
+    }
+    if (lane == 0) {
+        gA[s] += ga;
+        gB[s] += gb;
+        gC[s] += gc;
+    }
 }
 
 void launch_param_fwd(hipStream_t st, int kind, int nz, int nx, int nPml, int nPad, const float *A, const float *B, const float *C,
@@ -159,6 +194,9 @@ void launch_param_bwd(hipStream_t st, int kind, int nz, int nx, int nPml, int nP
     const int nzp = nz + 2 * nPml + nPad, nxp = nx + 2 * nPml;
     hipLaunchKernelGGL(k_param_bwd, dim3((nx + 63) / 64, (nz + 3) / 4), dim3(64, 4), 0, st, kind, nz, nx, nPml, nzp, nxp, A, B, C,
                        A_ref, B_ref, C_ref, Mask, gLam, gMu, gDen, gA, gB, gC);
+    const int rim = 2 * nx + 2 * (nz > 2 ? nz - 2 : 0);
+    hipLaunchKernelGGL(k_param_bwd_rim, dim3((rim + 3) / 4), dim3(256), 0, st, kind, nz, nx, nPml, nzp, nxp, A, B, C, A_ref, B_ref,
+                       C_ref, Mask, gLam, gMu, gDen, gA, gB, gC);
 }
 
 }  // namespace sepfwi
