@@ -70,6 +70,8 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     // on the pressure residual that is never injected, :430-433): computing something else than asked would be worse
     // than refusing.
     if (par.if_src_update) throw std::invalid_argument("parameter file: if_src_update is not supported");
+    if (par.if_win || par.has_filter || par.if_cross_misfit)
+        throw std::invalid_argument("parameter file: the data-conditioning keys if_win / filter / if_cross_misfit are not supported yet");
     HIP_OK(hipSetDevice(gpu_id_));
     HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
