@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: gpu_bench_profile.sh <tag>   -- the record run of a round: full bench line, rocprofv3 kernel-trace summary of the same
+# command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic.  Copies the summaries to gpurun_out/<tag>_*.
+TAG=${1:-r02}
+mkdir -p gpurun_out
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+( time timeout -k 10 600 python bench.py --steps 4 --warmup 1 ) > gpurun_out/${TAG}_bench_full.log 2>&1 || exit 1
+tail -4 gpurun_out/${TAG}_bench_full.log | cut -c1-900
+cd /tmp
+rm -rf $R/gpurun_out/prof_$TAG
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/trace -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/${TAG}_trace.log 2>&1 || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_$TAG/pmc_fetch -- python $R/bench.py --steps 1 --warmup 0 --nsteps 400 --no-cpu-baseline > $R/gpurun_out/${TAG}_fetch.log 2>&1 || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/prof_$TAG/pmc_write -- python $R/bench.py --steps 1 --warmup 0 --nsteps 400 --no-cpu-baseline > $R/gpurun_out/${TAG}_write.log 2>&1 || exit 1
+cd $R
+cp gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv gpurun_out/${TAG}_bench_kernel_stats.csv
+python scripts/pmc_summary.py gpurun_out/prof_$TAG/pmc_fetch > gpurun_out/${TAG}_bench_pmc_fetch.txt
+python scripts/pmc_summary.py gpurun_out/prof_$TAG/pmc_write > gpurun_out/${TAG}_bench_pmc_write.txt
+head -8 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-200
+head -14 gpurun_out/${TAG}_bench_pmc_fetch.txt
+# keep the raw kernel trace small enough to merge back: first shot group only
+ls -la gpurun_out/prof_$TAG/trace/*/ | head

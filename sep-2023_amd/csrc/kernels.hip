@@ -921,7 +921,7 @@ const OptField kOptFields[] = {
     {"batch", &KernelOptions::batch, 0, 2},       {"batch_f", &KernelOptions::batch_f, 0, 64},
     {"batch_b", &KernelOptions::batch_b, 0, 64},  {"batch_mb", &KernelOptions::batch_mb, 1, 1 << 20},
     {"batch_order", &KernelOptions::batch_order, 0, 1},
-    {"pipe_bwd", &KernelOptions::pipe_bwd, 0, 1}, {"probe", &KernelOptions::probe, 0, 1 << 30},
+    {"probe", &KernelOptions::probe, 0, 1 << 30},
 };
 }  // namespace
 

@@ -24,7 +24,6 @@ struct KernelOptions {
     int batch_f = 0, batch_b = 0;  // explicit forward / backward batch sizes (0: from batch_mb)
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
-    int pipe_bwd = 0;     // 1: backward of shot k overlaps the forward of shot k+1
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
 };
 KernelOptions kernel_options();                       // snapshot of the defaults

@@ -185,11 +185,6 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
 Session::~Session() {
     (void)hipSetDevice(gpu_id_);
     (void)hipDeviceSynchronize();
-    if (bwd_mem_.dvz_dz) (void)hipFree(bwd_mem_.dvz_dz);
-    for (int k = 0; k < 2; k++) {
-        if (ev_fwd_[k]) (void)hipEventDestroy(ev_fwd_[k]);
-        if (ev_bwd_[k]) (void)hipEventDestroy(ev_bwd_[k]);
-    }
     for (BLane &L : bl_) {
         if (L.state) (void)hipFree(L.state);
         if (L.bwd) (void)hipFree(L.bwd);
@@ -276,20 +271,6 @@ void Session::ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots) 
         d_stf_ = nullptr;
         HIP_OK(hipMalloc((void **)&d_stf_, need * sizeof(float)));
         d_stf_len_ = need;
-    }
-}
-
-// Memory variables of the backward pass when it overlaps a forward pass (pipe_bwd), plus the pipeline's events.
-void Session::ensure_bwd_mem() {
-    const size_t n = cells_;
-    if (bwd_mem_.dvz_dz) return;
-    float *b = nullptr;
-    HIP_OK(hipMalloc((void **)&b, 8 * n * sizeof(float)));
-    device_bytes_ += (long long)(8 * n * sizeof(float));
-    bwd_mem_ = PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
-    for (int k = 0; k < 2; k++) {
-        HIP_OK(hipEventCreateWithFlags(&ev_fwd_[k], hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&ev_bwd_[k], hipEventDisableTiming));
     }
 }
 
@@ -697,15 +678,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     };
     auto forward_inline = [&](const ShotCtx &c) { return c.line.n > 0 && !(c.comps & 1) && opt.line_fuse != 0; };
 
-    const bool scratch_any = withAdj && !par_.scratch_dir_name.empty();
-    const bool pipelined = withAdj && opt.pipe_bwd != 0 && fuse_bwd == 2 && group_size >= 2 && !scratch_any;
     // ---------------- batched mode: every launch advances a whole batch of shots ----------------
     // Batch sizes from the Infinity-Cache budget: a forward batch keeps 5 fields per shot + 5 media arrays resident, a
     // backward batch 15 arrays per shot + 5 (2000x500: 7 and 2; a 101x201 notebook problem: all its shots at once).  Where
     // not even two backward passes fit (2000x1000) the stream mode below runs the backward passes one by one.
     const double arr_mb = (double)n * sizeof(float) / 1.0e6, budget = (double)opt.batch_mb;
     int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
-    const bool batched = !pipelined && fuse_bwd == 2 && group_size >= 1 &&
+    const bool batched = fuse_bwd == 2 && group_size >= 1 &&
                          (opt.batch == 1 || (opt.batch == 2 && (withAdj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
     last_batched_ = batched;
     if (batched) {
@@ -834,67 +813,9 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                 launches_++;
             }
     }
-    if (pipelined) {
-        // Software pipeline over the shots of the call: while the backward pass of shot k runs on the main stream,
-        // the forward pass of shot k+1 runs on the second stream in the other lane (fields, memory variables,
-        // boundary frames, seismograms, residual are per lane; the backward pass has its own memory variables).
-        // Working set = 5 (forward lane) + 15 (backward) + 5 (media) arrays of 9 MB: still inside the 256 MB
-        // Infinity Cache, and each pass fills the kernel-boundary gaps and tails of the other.
-        ensure_lanes(2, true);
-        ensure_bwd_mem();
-        hipStream_t s2 = xl_[1].stream;
-        HIP_OK(hipEventRecord(ev_[0], st));
-        HIP_OK(hipStreamWaitEvent(s2, ev_[0], 0));
-        ShotCtx cur = make_ctx(0, 0, s2);
-        {
-            const bool inl = forward_inline(cur);
-            forward_init(cur);
-            for (int it = 0; it <= nSteps - 2; it++) forward_step(cur, it, inl);
-            if (inl) forward_last_column(cur);
-            residual(cur);
-            HIP_OK(hipEventRecord(ev_fwd_[0], s2));
-        }
-        for (int k = 0; k < group_size; k++) {
-            const bool has_next = k + 1 < group_size;
-            ShotCtx nxt{};
-            bool inl = false;
-            if (has_next) {
-                nxt = make_ctx(k + 1, (k + 1) & 1, s2);
-                inl = forward_inline(nxt);
-                if (k >= 1) HIP_OK(hipStreamWaitEvent(s2, ev_bwd_[(k + 1) & 1], 0));  // that lane's previous shot is fully consumed
-                forward_init(nxt);
-            }
-            HIP_OK(hipStreamWaitEvent(st, ev_fwd_[k & 1], 0));
-            const BwdLane BL{st, bwd_mem_, adj_, acc_};
-            backward_init(BL);
-            for (int j = 0; j <= nSteps - 2; j++) {
-                backward_step(cur, BL, nSteps - 2 - j);
-                if (has_next) forward_step(nxt, j, inl);
-            }
-            HIP_OK(hipEventRecord(ev_bwd_[k & 1], st));
-            if (has_next) {
-                if (inl) forward_last_column(nxt);
-                residual(nxt);
-                HIP_OK(hipEventRecord(ev_fwd_[(k + 1) & 1], s2));
-            }
-            cur = nxt;
-        }
-        HIP_OK(hipEventRecord(ev_[1], st));
-        fwd_steps_ += (long long)group_size * (nSteps - 1);
-        bwd_steps_ += (long long)group_size * (nSteps - 1);
-        HIP_OK(hipStreamSynchronize(st));
-        HIP_OK(hipStreamSynchronize(s2));
-        collect_probes();
-        float ms = 0.f;
-        HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-        // forward and backward overlap: apportion the wall time by algorithmic bytes (60 : 124) for the statistics
-        fwd_ms_ += ms * (60.0 / 184.0);
-        bwd_ms_ += ms * (124.0 / 184.0);
-    }
-
     // ---------------- stream mode: up to fwd_lanes forward passes side by side, then their backward passes ----------------
-    if (!pipelined && !batched && n_lanes >= 2) ensure_lanes(n_lanes, withAdj);
-    for (int is = 0; is < group_size && !pipelined && !batched;) {
+    if (!batched && n_lanes >= 2) ensure_lanes(n_lanes, withAdj);
+    for (int is = 0; is < group_size && !batched;) {
         const int np = std::min(n_lanes, group_size - is);
         ShotCtx ctx[kMaxLanes];
         ctx[0] = make_ctx(is, 0, st);

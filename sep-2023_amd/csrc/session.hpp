@@ -46,7 +46,6 @@ class Session {
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
-    void ensure_bwd_mem();
     void order_after_null_stream(hipStream_t st);
 
     struct ObsEntry {
@@ -83,8 +82,6 @@ class Session {
         hipEvent_t join = nullptr;
     };
     XLane xl_[kMaxLanes];
-    hipEvent_t ev_fwd_[2] = {nullptr, nullptr}, ev_bwd_[2] = {nullptr, nullptr};
-    PmlMem bwd_mem_{};  // backward-pass memory variables of the pipelined mode
     size_t stf_grad_len_ = 0;
     // batched mode: lanes of per-shot state (forward: fields + memories, frames, seismograms, residual; backward: memories,
     // adjoint fields, accumulators) and the device table of the call's shots
