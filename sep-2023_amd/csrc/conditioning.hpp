@@ -1,0 +1,41 @@
+// conditioning.hpp -- data-conditioning chain of the misfit (conditioning.hip): windows, band-pass (hipFFT), normalised
+// cross-correlation misfit.  All gathers are [rec][nt] float32 device arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+
+namespace sepfwi {
+
+class Conditioner {
+  public:
+    Conditioner(int nt, int max_nrec);
+    ~Conditioner();
+    Conditioner(const Conditioner &) = delete;
+    Conditioner &operator=(const Conditioner &) = delete;
+
+    // cuda_window (utilities.cu:787-884): win_start == nullptr -> one end taper for all traces; else per-trace windows
+    // [win_start, win_end] in seconds and amplitude weights[r] * src_weight.  ratio: libCUFD.cu:63 (0.005).
+    void window(hipStream_t st, float *data, int nrec, float dt, const float *win_start, const float *win_end, const float *weights,
+                float src_weight, float ratio);
+    // bp_filter1d (utilities.cu:1115-1166): zero-phase sin^2 / cos^2 band-pass with corners filt[0..3] Hz, in place
+    void bandpass(hipStream_t st, float *data, int nrec, float dt, const float filt[4]);
+    // gpuMinus + cuda_cal_objective (utilities.cu:154-205): res = obs - syn (first sample zeroed), *acc += sum res^2
+    void l2_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, double *acc);
+    // cuda_find_normfact x3 + cuda_normal_misfit + cuda_normal_adjoint_source (utilities.cu:1010-1111):
+    // *acc += -2 sum_r <obs,syn>_r / (|obs|_r |syn|_r) w_r ; res = the adjoint source.  weights may be null (all ones).
+    void cross_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, const float *weights, float src_weight,
+                        double *acc);
+    long long device_bytes() const;
+
+  private:
+    struct Plans {
+        void *fwd, *inv;  // hipfftHandle
+    };
+    int nt_, cap_;
+    float *pad_ = nullptr, *norm_ = nullptr;
+    void *spec_ = nullptr;  // hipfftComplex [cap][nt + 1]
+    std::map<int, Plans> plans_;  // by number of traces
+};
+
+}  // namespace sepfwi

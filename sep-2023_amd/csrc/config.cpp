@@ -38,6 +38,13 @@ Params parse_params(const std::string &text) {
     if (j.has("if_src_update")) p.if_src_update = j.at("if_src_update").as_bool("if_src_update");
     if (j.has("if_cross_misfit")) p.if_cross_misfit = j.at("if_cross_misfit").as_bool("if_cross_misfit");
     p.has_filter = j.has("filter");
+    if (p.has_filter) {
+        const JsonValue &f = j.at("filter");
+        if (f.kind != JsonValue::Array || f.arr.size() != 4) throw std::runtime_error("parameter JSON: filter must be [f0, f1, f2, f3]");
+        for (int k = 0; k < 4; k++) p.filter[k] = (float)f.arr[k].as_number("filter[]");
+        if (!(p.filter[0] <= p.filter[1] && p.filter[1] <= p.filter[2] && p.filter[2] <= p.filter[3]))
+            throw std::runtime_error("parameter JSON: filter corners must be ascending");
+    }
     if (j.has("das_fiber")) {
         const std::string f = j.at("das_fiber").as_string("das_fiber");
         if (f == "vertical")
@@ -54,7 +61,7 @@ Params parse_params(const std::string &text) {
     return p;
 }
 
-Survey parse_survey(const std::string &text, int nPml) {
+Survey parse_survey(const std::string &text, int nPml, bool if_win) {
     JsonValue j = JsonReader(text).parse();
     if (j.kind != JsonValue::Object) throw std::runtime_error("survey JSON is not an object");
     Survey s;
@@ -84,6 +91,19 @@ Survey parse_survey(const std::string &text, int nPml) {
             sh.x_rec[r] = xr.arr[r].as_int("x_rec[]") + nPml;
         }
         if (js.has("src_rxz")) sh.src_rxz = js.at("src_rxz").as_number("src_rxz");
+        auto floats = [&](const char *key, std::vector<float> &out) {
+            const JsonValue &a = js.at(key);
+            if (a.kind != JsonValue::Array || (int)a.arr.size() < sh.nrec)
+                throw std::runtime_error(std::string("survey JSON: ") + key + " shorter than nrec for " + kv.first);
+            out.resize(sh.nrec);
+            for (int r = 0; r < sh.nrec; r++) out[r] = (float)a.arr[r].as_number(key);
+        };
+        if (if_win) {  // Src_Rec.cu:144-174: both arrays are mandatory with if_win
+            floats("win_start", sh.win_start);
+            floats("win_end", sh.win_end);
+        }
+        if (js.has("weights")) floats("weights", sh.weights);                                    // Src_Rec.cu:176-192
+        if (js.has("src_weight")) sh.src_weight = (float)js.at("src_weight").as_number("src_weight");  // :195-200
         if (js.has("das_sensitivity")) {
             const JsonValue &ds = js.at("das_sensitivity");
             if (ds.kind != JsonValue::Array || (int)ds.arr.size() < sh.nrec)

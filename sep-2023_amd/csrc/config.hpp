@@ -12,7 +12,9 @@ struct Params {
     float dz = 0, dx = 0, dt = 0, f0 = 0;
     int nSteps = 0, nPml = 0, nPad = 0;
     std::string survey_fname, data_dir_name, scratch_dir_name;
+    // data-conditioning keys (dormant in the reference's driver, libCUFD.cu:353-457; live here, csrc/conditioning.hip)
     bool if_win = false, if_src_update = false, if_cross_misfit = false, has_filter = false;
+    float filter[4] = {0, 0, 0, 0};  // band-pass corner frequencies [Hz]   (Parameter.cpp:147-159)
     // optional key "das_fiber": "horizontal" (default; recording_exx / res_injection_exx, libCUFD.cu:325,607) or
     // "vertical" (recording_ezz / res_injection_ezz, utilities.cu:620-641 -- in the reference a source edit)
     int fiber = 0;
@@ -27,6 +29,9 @@ struct Shot {
     // MOD/elasticSolver.py:152-153,276): per-channel directional sensitivities, stored as (s_xx, s_zz, s_xz) triples.
     // Empty: straight fibre along x or z (para key "das_fiber").
     std::vector<float> sens;
+    // with if_win: per-channel time windows [s] and trace weights, shot weight (Src_Rec.cu:144-200); weights default to 1
+    std::vector<float> win_start, win_end, weights;
+    float src_weight = 1.0f;
     bool present = false;
 };
 
@@ -42,7 +47,7 @@ std::string read_first_line(const std::string &fname);
 
 // Parse; throw std::runtime_error on malformed input.
 Params parse_params(const std::string &json_text);
-Survey parse_survey(const std::string &json_text, int nPml);
+Survey parse_survey(const std::string &json_text, int nPml, bool if_win = false);
 
 // C-PML 1-D profiles (replaces cpmlInit, Src/utilities.cu:243-359).
 void cpml_profiles(float *K, float *a, float *b, float *K_half, float *a_half, float *b_half, int N, int nPml,

@@ -70,8 +70,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     // on the pressure residual that is never injected, :430-433): computing something else than asked would be worse
     // than refusing.
     if (par.if_src_update) throw std::invalid_argument("parameter file: if_src_update is not supported");
-    if (par.if_win || par.has_filter || par.if_cross_misfit)
-        throw std::invalid_argument("parameter file: the data-conditioning keys if_win / filter / if_cross_misfit are not supported yet");
+    cond_on_ = par.if_win || par.has_filter || par.if_cross_misfit;
     HIP_OK(hipSetDevice(gpu_id_));
     HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
@@ -174,11 +173,33 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
             HIP_OK(hipMemcpy(sens_, sv.data(), sv.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
+    if (cond_on_) {  // [start | end | weight] per channel; without if_win only the weights matter (cross-correlation misfit)
+        const int ns = (int)survey_.shots.size();
+        const size_t tot = (size_t)rec_off_[ns] + 1;
+        std::vector<float> w(3 * tot, 0.0f);
+        for (int i = 0; i < ns; i++) {
+            const Shot &sh = survey_.shots[i];
+            if (!sh.present) continue;
+            for (int r = 0; r < sh.nrec; r++) {
+                const size_t k = (size_t)rec_off_[i] + r;
+                w[k] = sh.win_start.empty() ? 0.0f : sh.win_start[r];
+                w[tot + k] = sh.win_end.empty() ? 0.0f : sh.win_end[r];
+                w[2 * tot + k] = sh.weights.empty() ? 1.0f : sh.weights[r];
+            }
+        }
+        win_ = dalloc<float>(w.size());
+        HIP_OK(hipMemcpy(win_, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     const size_t dlen = (size_t)std::max(1, survey_.max_nrec) * (size_t)par.nSteps;
     data_len_ = dlen;
     syn_ = dalloc<float>(4 * dlen);  // time-major pr, vx, vz, ett
     res_ = dalloc<float>(dlen);
     xpose_ = dalloc<float>(dlen);
+    if (cond_on_) {
+        xpose2_ = dalloc<float>(dlen);
+        cond_.reset(new Conditioner(par.nSteps, std::max(1, survey_.max_nrec)));
+        device_bytes_ += cond_->device_bytes();
+    }
     HIP_OK(hipHostMalloc((void **)&h_io_, dlen * sizeof(float), hipHostMallocDefault));
 }
 
@@ -313,7 +334,12 @@ void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) 
         hipStream_t st = own_stream_;
         order_after_null_stream(st);  // a HIP `ett` was produced on the caller's (default) stream
         HIP_OK(hipMemcpyAsync(xpose_, ett, want, hipMemcpyDefault, st));
-        launch_transpose(st, xpose_, e.d_ett, nrec, nSteps);  // [rec][it] -> [it][rec]
+        if (cond_on_) {  // kept conditioned and trace-major
+            condition_gather(st, xpose_, shot_id, nrec);
+            HIP_OK(hipMemcpyAsync(e.d_ett, xpose_, want, hipMemcpyDeviceToDevice, st));
+        } else {
+            launch_transpose(st, xpose_, e.d_ett, nrec, nSteps);  // [rec][it] -> [it][rec]
+        }
         HIP_OK(hipStreamSynchronize(st));
     }
     obs_[shot_id] = e;
@@ -359,10 +385,27 @@ const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
     e.size = (long long)sb.st_size;
     e.mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec;
     HIP_OK(hipMemcpyAsync(xpose_, h_io_, want, hipMemcpyHostToDevice, st));
-    launch_transpose(st, xpose_, e.d_ett, nrec, par_.nSteps);  // [rec][it] -> [it][rec]
+    if (cond_on_) {  // kept conditioned and trace-major
+        condition_gather(st, xpose_, shot_id, nrec);
+        HIP_OK(hipMemcpyAsync(e.d_ett, xpose_, want, hipMemcpyDeviceToDevice, st));
+    } else {
+        launch_transpose(st, xpose_, e.d_ett, nrec, par_.nSteps);  // [rec][it] -> [it][rec]
+    }
     HIP_OK(hipStreamSynchronize(st));
     obs_[shot_id] = e;
     return e.d_ett;
+}
+
+// Window and band-pass one [rec][it] gather in place, as the commented driver lines apply them to observed and synthetic
+// data alike (libCUFD.cu:353-374): per-channel windows with weights when if_win, else the plain end taper; then the filter.
+void Session::condition_gather(hipStream_t st, float *gather, int shot_id, int nrec) {
+    const size_t tot = (size_t)rec_off_.back() + 1, off = (size_t)rec_off_[shot_id];
+    const Shot &sh = survey_.shots[shot_id];
+    if (par_.if_win)
+        cond_->window(st, gather, nrec, par_.dt, win_ + off, win_ + tot + off, win_ + 2 * tot + off, sh.src_weight, 0.005f);
+    else
+        cond_->window(st, gather, nrec, par_.dt, nullptr, nullptr, nullptr, 1.0f, 0.005f);
+    if (par_.has_filter) cond_->bandpass(st, gather, nrec, par_.dt, par_.filter);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,6 +592,25 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
         launch_residual(c.st, c.d_obs, syn_of(c, 3), c.res, c.nrec, (long long)c.nrec * nSteps, scal_);
         launches_++;
+    };
+    // the same with the data-conditioning chain (libCUFD.cu:353-457 as its commented lines compose it), on the MAIN stream:
+    // the scratch gathers and the FFT work space are shared by the shots of a call
+    auto residual_conditioned = [&](const ShotCtx &c) {
+        if (c.nrec <= 0) return;
+        const size_t tot = (size_t)rec_off_.back() + 1, off = (size_t)rec_off_[c.id];
+        launch_transpose(st, syn_of(c, 3), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
+        condition_gather(st, xpose_, c.id, c.nrec);
+        if (par_.if_cross_misfit)
+            cond_->cross_residual(st, c.d_obs, xpose_, xpose2_, c.nrec, win_ + 2 * tot + off, c.sh->src_weight, scal_);
+        else
+            cond_->l2_residual(st, c.d_obs, xpose_, xpose2_, c.nrec, scal_);
+        if (par_.has_filter) cond_->bandpass(st, xpose2_, c.nrec, par_.dt, par_.filter);  // adjoint of the (zero-phase) filter
+        if (par_.if_win)
+            cond_->window(st, xpose2_, c.nrec, par_.dt, win_ + off, win_ + tot + off, win_ + 2 * tot + off, c.sh->src_weight, 0.005f);
+        else
+            cond_->window(st, xpose2_, c.nrec, par_.dt, nullptr, nullptr, nullptr, 1.0f, 0.005f);
+        launch_transpose(st, xpose2_, c.res, c.nrec, nSteps);  // [rec][it] -> [it][rec]: the adjoint source
+        launches_ += 8;
     };
     auto export_gathers = [&](const ShotCtx &c) {
         // observe: export the four gathers as [nrec][nSteps] files (libCUFD.cu:755-769)
@@ -759,7 +821,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             for (int k = 0; k < nb; k++)
                 if (tab[is0 + k].comps & 16) forward_last_column(cx[k]);
             if (if_res)
-                for (int k = 0; k < nb; k++) residual(cx[k]);
+                for (int k = 0; k < nb; k++) cond_on_ ? residual_conditioned(cx[k]) : residual(cx[k]);
             HIP_OK(hipEventRecord(ev_[1], st));
             fwd_steps_ += (long long)nb * (nSteps - 1);
             HIP_OK(hipStreamSynchronize(st));
@@ -831,12 +893,14 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
         for (int k = 0; k < np; k++)
             if (inl[k]) forward_last_column(ctx[k]);
-        if (if_res)
+        if (if_res && !cond_on_)
             for (int k = 0; k < np; k++) residual(ctx[k]);
         for (int k = 1; k < np; k++) {  // join: the main stream continues when the extra lanes are done
             HIP_OK(hipEventRecord(xl_[k].join, xl_[k].stream));
             HIP_OK(hipStreamWaitEvent(st, xl_[k].join, 0));
         }
+        if (if_res && cond_on_)
+            for (int k = 0; k < np; k++) residual_conditioned(ctx[k]);
         HIP_OK(hipEventRecord(ev_[1], st));
         fwd_steps_ += (long long)np * (nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));
@@ -945,7 +1009,7 @@ std::shared_ptr<Session> get_session(const std::string &para_fname, int gpu_id) 
     auto it = g_sessions.find(key);
     if (it != g_sessions.end() && it->second->matches(ptext, stext)) return it->second;
     if (it != g_sessions.end()) g_sessions.erase(it);  // a thread still inside run() keeps its own reference
-    Survey sv = parse_survey(stext, par.nPml);
+    Survey sv = parse_survey(stext, par.nPml, par.if_win);
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (gpu_id < 0 || gpu_id >= ndev)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/sepfwi.h"
+#include "conditioning.hpp"
 #include "config.hpp"
 #include "fwi_types.hpp"
 #include "kernels.hpp"
@@ -47,9 +48,10 @@ class Session {
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void order_after_null_stream(hipStream_t st);
+    void condition_gather(hipStream_t st, float *gather_rec_major, int shot_id, int nrec);
 
     struct ObsEntry {
-        float *d_ett = nullptr;  // [nSteps][nrec]
+        float *d_ett = nullptr;  // [nSteps][nrec]; with data conditioning: the CONDITIONED gather, [nrec][nSteps]
         size_t bytes = 0;
         long long size = 0, mtime_ns = 0;
         bool from_memory = false;  // handed over through sepfwi_set_observed: no file behind it
@@ -100,6 +102,11 @@ class Session {
     unsigned int *cp2_bits_ = nullptr;
     int *rec_idx_ = nullptr;
     float *sens_ = nullptr;  // directional DAS sensitivities (3 per channel) or null
+    // data conditioning (parameter keys if_win / filter / if_cross_misfit): per-channel windows and weights (3 per channel:
+    // start, end, weight; same offsets as rec_idx_), a second [rec][it] scratch gather, the hipFFT work space
+    bool cond_on_ = false;
+    float *win_ = nullptr, *xpose2_ = nullptr;
+    std::unique_ptr<Conditioner> cond_;
     std::vector<int> rec_off_;
     Fields fld_{}, adj_{};
     PmlMem mem_{};

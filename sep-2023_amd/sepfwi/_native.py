@@ -12,8 +12,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
-SOURCES = ["kernels.hip", "param_maps.hip", "session.cpp", "config.cpp", "capi.cpp"]
-HEADERS = ["kernels.hpp", "param_maps.hpp", "device_common.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "config.cpp", "capi.cpp"]
+HEADERS = ["kernels.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
 _lib = None
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -ffp-contract=off: no fused multiply-adds chosen per kernel by the compiler, so every kernel structure (stream, batched,
     # unfused, persistent) gives bit-identical results; the kernels are memory-bound, it costs nothing
     extra = os.environ.get("SEPFWI_HIPCC_FLAGS", "").split()   # experiments only (e.g. -fgpu-flush-denormals-to-zero)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + extra + ["-o", LIB_PATH] + SOURCES
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + extra + ["-o", LIB_PATH] + SOURCES + ["-lhipfft"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -65,7 +65,8 @@ def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname
         json.dump(para, fp)
 
 
-def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Src_Weights=None, Src_rxz=None, Rec_rxz=None, Das_sensitivity=None):
+def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Windows=None, Weights=None, Src_Weights=None, Src_rxz=None, Rec_rxz=None,
+              Das_sensitivity=None):
     """Write the one-line survey JSON: every shot shares the receiver list; indices are UNPADDED grid
     indices (fwi_utils.py:87-124).
     Das_sensitivity (extension): (nrec, 6) directional sensitivities of the DAS channels in the layout of
@@ -80,6 +81,11 @@ def surveyGen(z_src, x_src, z_rec, x_rec, survey_fname, Src_Weights=None, Src_rx
     for i in range(len(x_src)):
         shot = {"z_src": int(z_src[i]), "x_src": int(x_src[i]), "nrec": len(x_rec),
                 "z_rec": [int(v) for v in z_rec], "x_rec": [int(v) for v in x_rec]}
+        if Windows is not None:
+            shot["win_start"] = [float(v) for v in Windows["shot%d" % i]["start"]]
+            shot["win_end"] = [float(v) for v in Windows["shot%d" % i]["end"]]
+        if Weights is not None:
+            shot["weights"] = [float(v) for v in Weights["shot%d" % i]["weights"]]
         if Src_Weights is not None:
             shot["src_weight"] = Src_Weights[i]
         if Src_rxz is not None:
