@@ -184,10 +184,21 @@ def main():
         Stf = pb["Stf"]
         # shot ids: step s uses the block [s*world*spr, (s+1)*world*spr); rank r owns the r-th contiguous group of spr shots
         my_ids = [s * world * spr + rank * spr + j for s in range(per_rank_steps) for j in range(spr)]
-        # observed data for my shots (untimed set-up; each rank writes its own files, then caches them in HBM)
+        # observed data for my shots (untimed set-up): modelled in groups of `spr` shots, handed to the session's HBM store
+        # (sepfwi_set_observed) and the four gather files of each shot deleted again -- a long run (steps x shots x 127 MB,
+        # times N ranks) must not fill the node's /tmp
         from sepfwi import dist as _dist
+        from sepfwi import utils as ft
         _cufd = fwi_ops._cufd
-        _cufd(2, local, lam_t, mu_t, den_t, Stf, torch.tensor(my_ids, dtype=torch.int32), pb["para_fname"])
+        data_dir = os.path.join(workdir, "Data")
+        for k in range(0, len(my_ids), spr):
+            grp = my_ids[k:k + spr]
+            _cufd(2, local, lam_t, mu_t, den_t, Stf, torch.tensor(grp, dtype=torch.int32), pb["para_fname"])
+            for sid in grp:
+                ett = torch.from_numpy(ft.read_shot_gather(data_dir, "ett", sid, args.nsteps).copy())
+                fwi_ops.set_observed(pb["para_fname"], sid, ett, gpu_id=local)
+                for c in ("pr", "vx", "vz", "ett"):
+                    os.remove(os.path.join(data_dir, "Shot_%s%d.bin" % (c, sid)))
         del lam_t, mu_t, den_t
 
         def step(s):

@@ -15,7 +15,7 @@ NC = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 NZ = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
 dev = torch.device("cuda", 0)
 from sepfwi import _native
-for kv in os.environ.get("SEPFWI_OPTS", "").split(","):   # e.g. SEPFWI_OPTS=fwd_fuse=1,pair_fwd=0
+for kv in os.environ.get("SEPFWI_OPTS", "").split(","):   # e.g. SEPFWI_OPTS=batch=0,pair_fwd=0
     if kv:
         _native.check(_native.lib().sepfwi_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 works = [tempfile.mkdtemp(prefix="sepfwi_cc%d_" % i) for i in range(NC)]

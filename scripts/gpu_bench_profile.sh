@@ -18,4 +18,7 @@ python scripts/pmc_summary.py gpurun_out/prof_$TAG/pmc_write > gpurun_out/${TAG}
 head -8 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-200
 head -14 gpurun_out/${TAG}_bench_pmc_fetch.txt
 # keep the raw kernel trace small enough to merge back: first shot group only
-ls -la gpurun_out/prof_$TAG/trace/*/ | head
+rm -f gpurun_out/prof_$TAG/trace/*/*kernel_trace.csv   # 22 MB raw trace: the stats csv is what is kept
+# configs[1] shape, forward only, un-profiled
+( timeout -k 10 300 python bench.py --mode fwd --nz 500 --nsteps 2000 --steps 3 --warmup 1 --no-cpu-baseline ) > gpurun_out/${TAG}_fwd2000x500_bench.log 2>&1
+tail -1 gpurun_out/${TAG}_fwd2000x500_bench.log | cut -c1-400

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/traffic.json from the two PMC summaries of the bench command (scripts/gpu_run7.sh):
+"""profiles/traffic.json from the two PMC summaries of the bench command (scripts/gpu_bench_profile.sh):
 HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB."""
 import json
 import os
@@ -22,12 +22,12 @@ def parse(path, counter):
     return out
 
 
-fetch = parse(os.path.join(ROOT, "profiles", "r01_bench_pmc_fetch.txt"), "FETCH_SIZE")
-write = parse(os.path.join(ROOT, "profiles", "r01_bench_pmc_write.txt"), "WRITE_SIZE")
+fetch = parse(os.path.join(ROOT, "profiles", "r02_bench_pmc_fetch.txt"), "FETCH_SIZE")
+write = parse(os.path.join(ROOT, "profiles", "r02_bench_pmc_write.txt"), "WRITE_SIZE")
 keys = {"k_bwd_b": "k_bwd_b", "k_bwd_a": "k_bwd_a", "k_stress<true, true>": "k_stress_fwd_save", "k_velocity<true>": "k_velocity_fwd"}
 res = {"_how": "rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE on `python bench.py --steps 1 --warmup 0 --nsteps 400 "
-               "--no-cpu-baseline` (profiles/r01_bench_pmc_fetch.txt, r01_bench_pmc_write.txt); FETCH_SIZE doubled per the gfx950 "
-               "correction of MI355X_MICROARCH.md (calibrated on k_fwd_fused: 10 arrays x 9.19 MB = 91.9 MB compulsory vs 2 x 45.1 MB "
+               "--no-cpu-baseline` (profiles/r02_bench_pmc_fetch.txt, r02_bench_pmc_write.txt); FETCH_SIZE doubled per the gfx950 "
+               "correction of MI355X_MICROARCH.md (calibrated in round 1 on a kernel with known compulsory bytes: 10 arrays x 9.19 MB = 91.9 MB vs 2 x 45.1 MB "
                "counted), WRITE_SIZE as counted; KiB -> bytes.  Regenerate with scripts/make_traffic_json.py."}
 for pat, key in keys.items():
     f = [v for k, v in fetch.items() if pat in k]
