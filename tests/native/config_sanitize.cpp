@@ -36,6 +36,16 @@ int main(int argc, char **argv) {
         printf("FAIL: reference documents mis-parsed\n");
         return 1;
     }
+    // keys that merely start with "shot" are not shots; ids beyond nShots are ignored like the reference's reader does
+    // (Src_Rec.cu:78 loops i < group_size over "shot" + to_string(id))
+    {
+        Survey q = parse_survey("{\"nShots\": 1, \"shots_meta\": {\"z_src\": 1}, \"shot-3\": 5, \"shot7\": {\"z_src\": 1}, "
+                                "\"shot0\": {\"z_src\": 2, \"x_src\": 5, \"nrec\": 0, \"z_rec\": [], \"x_rec\": []}}", 10);
+        if (q.shots.size() != 1 || !q.shots[0].present || q.shots[0].z_src != 12) {
+            printf("FAIL: shot key validation\n");
+            return 1;
+        }
+    }
     // 2. mutated documents either parse or throw std::exception -- never crash, overflow or leak
     std::mt19937 rng(seed);
     const std::string docs[2] = {PARA, SURVEY};

@@ -288,3 +288,22 @@ def test_rock_physics_maps_match_reference_vectors(monkeypatch, tmp_path):
     fwi(pb["Shot_ids"], ngpu=1).backward()
     assert [n for n, _ in fwi.named_parameters()] == ["PHI", "CC", "SW"]
     assert all(torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in fwi.parameters())
+
+
+def test_wrong_shapes_are_refused_before_the_library_sees_them(tmp_path):
+    """The C ABI carries no sizes (like the reference's raw data_ptr<float>() hand-over, Src/Torch_Fwi.cpp:55-58): the wrapper
+    checks tensors against the parameter file, so a wrong shape is a ValueError and not an out-of-bounds read or write."""
+    from sepfwi import fwi_ops
+    pb = P.make_problem(str(tmp_path), nSteps=40, nshots=2)
+    lam, mu, den = pb["lame_init"]
+    ok = dict(Lambda=lam, Mu=mu, Den=den, Stf=pb["Stf"], ids=pb["Shot_ids"])
+    bad = [dict(ok, Lambda=lam[:-1], Mu=mu[:-1], Den=den[:-1]),              # model of another grid
+           dict(ok, Mu=mu[:, :-1].contiguous()),                             # three different shapes
+           dict(ok, Stf=pb["Stf"][:, :-3].contiguous()),                     # gStf would be written past its end
+           dict(ok, ids=torch.tensor([0, 2], dtype=torch.int32)),            # row 2 of a two-row Stf
+           dict(ok, ids=torch.tensor([-1], dtype=torch.int32))]
+    for a in bad:
+        with pytest.raises(ValueError):
+            fwi_ops._cufd(1, 0, a["Lambda"], a["Mu"], a["Den"], a["Stf"], a["ids"], pb["para_fname"])
+    with pytest.raises(TypeError):
+        fwi_ops._cufd(1, 0, lam.double(), mu, den, pb["Stf"], pb["Shot_ids"], pb["para_fname"])
