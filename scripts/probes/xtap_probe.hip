@@ -7,6 +7,8 @@
 //   variant 0: every tap is a global load (shifted loads hit the same lines in the vector L1)      [what the product does]
 //   variant 1: the x-taps of a wave come from its own registers through ds_bpermute (__shfl); only the 2+2 edge lanes load
 //   variant 2: x-taps through DPP wave shifts (wave_shr / wave_shl, 1 and 2 lanes), edge lanes load
+//   variant 3: FOUR columns per lane (16-byte loads, a wave covers 256 columns): a quarter of the vector-memory instructions,
+//              x-taps mostly from the lane's own registers, 1-2 halo values per lane and array by (cached) loads
 // Prints microseconds per launch (mean of the back half of 400 launches) and the checksum of the result (equal for all).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o xtap_probe xtap_probe.hip && ./xtap_probe
 #include <hip/hip_runtime.h>
@@ -83,6 +85,50 @@ __global__ __launch_bounds__(1024) void k_update(const float *__restrict__ szz, 
     vx[i] = vx[i] + (dsxz_dz + dsxx_dx) * bb * 1e-3f;
 }
 
+// variant 3: four consecutive columns per lane
+__global__ __launch_bounds__(1024) void k_update4(const float *__restrict__ szz, const float *__restrict__ sxz, const float *__restrict__ sxx,
+                                                  const float *__restrict__ rho, float *__restrict__ vz, float *__restrict__ vx, int gx4, int gy) {
+    int t = blockIdx.x;
+    const int per = (gx4 * gy + 7) >> 3;
+    t = (t & 7) * per + (t >> 3);
+    const int ty = t / gx4, tx = t - ty * gx4;
+    const int x = tx * 256 + 4 * (threadIdx.x & 63);
+    const int z = __builtin_amdgcn_readfirstlane(ty * 2 + (int)(threadIdx.x >> 6));
+    if (ty >= gy || z < 2 || z > NZ - 3 || x >= P) return;
+    const size_t i = (size_t)z * P + x;
+    auto ld4 = [](const float *p) { return *reinterpret_cast<const float4 *>(p); };
+    const float4 zz_m1 = ld4(szz + i - P), zz_0 = ld4(szz + i), zz_p1 = ld4(szz + i + P), zz_p2 = ld4(szz + i + 2 * P);
+    const float4 xz_m2 = ld4(sxz + i - 2 * P), xz_m1 = ld4(sxz + i - P), xz_0 = ld4(sxz + i), xz_p1 = ld4(sxz + i + P);
+    const float4 xx_0 = ld4(sxx + i), r_0 = ld4(rho + i), r_p = ld4(rho + i + P);
+    const bool left = x >= 2, right = x + 5 < P;
+    const float xz_l2 = left ? sxz[i - 2] : 0.f, xz_l1 = left ? sxz[i - 1] : 0.f, xz_r = right ? sxz[i + 4] : 0.f;
+    const float xx_l1 = left ? sxx[i - 1] : 0.f, xx_r1 = right ? sxx[i + 4] : 0.f, xx_r2 = right ? sxx[i + 5] : 0.f;
+    const float r_r = right ? rho[i + 4] : 1.f;
+    float4 v_z = ld4(vz + i), v_x = ld4(vx + i);
+    const float a_xz[7] = {xz_l2, xz_l1, xz_0.x, xz_0.y, xz_0.z, xz_0.w, xz_r};
+    const float a_xx[7] = {xx_l1, xx_0.x, xx_0.y, xx_0.z, xx_0.w, xx_r1, xx_r2};
+    const float a_r[5] = {r_0.x, r_0.y, r_0.z, r_0.w, r_r};
+    const float zzm1[4] = {zz_m1.x, zz_m1.y, zz_m1.z, zz_m1.w}, zz0[4] = {zz_0.x, zz_0.y, zz_0.z, zz_0.w}, zzp1[4] = {zz_p1.x, zz_p1.y, zz_p1.z, zz_p1.w},
+                zzp2[4] = {zz_p2.x, zz_p2.y, zz_p2.z, zz_p2.w};
+    const float xzm2[4] = {xz_m2.x, xz_m2.y, xz_m2.z, xz_m2.w}, xzm1[4] = {xz_m1.x, xz_m1.y, xz_m1.z, xz_m1.w}, xzp1[4] = {xz_p1.x, xz_p1.y, xz_p1.z, xz_p1.w};
+    const float rp[4] = {r_p.x, r_p.y, r_p.z, r_p.w};
+    float oz[4] = {v_z.x, v_z.y, v_z.z, v_z.w}, ox[4] = {v_x.x, v_x.y, v_x.z, v_x.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int xc = x + k;
+        if (xc < 2 || xc > NX - 3) continue;
+        const float dszz_dz = dplus(zzm1[k], zz0[k], zzp1[k], zzp2[k]);
+        const float dsxz_dz = dminus(xzm2[k], xzm1[k], a_xz[k + 2], xzp1[k]);
+        const float dsxz_dx = dminus(a_xz[k], a_xz[k + 1], a_xz[k + 2], a_xz[k + 3]);
+        const float dsxx_dx = dplus(a_xx[k], a_xx[k + 1], a_xx[k + 2], a_xx[k + 3]);
+        const float ba = 2.0f / (rp[k] + a_r[k]), bb = 2.0f / (a_r[k + 1] + a_r[k]);
+        oz[k] = oz[k] + (dszz_dz + dsxz_dx) * ba * 1e-3f;
+        ox[k] = ox[k] + (dsxz_dz + dsxx_dx) * bb * 1e-3f;
+    }
+    *reinterpret_cast<float4 *>(vz + i) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+    *reinterpret_cast<float4 *>(vx + i) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+}
+
 int main() {
     const size_t n = (size_t)(NZ + 4) * P;
     float *d[6];
@@ -101,7 +147,8 @@ int main() {
     hipEvent_t e0, e1;
     OK(hipEventCreate(&e0));
     OK(hipEventCreate(&e1));
-    for (int var = 0; var < 3; var++) {
+    const int gx4 = (NX + 255) / 256, nb4 = ((gx4 * gy + 7) / 8) * 8;
+    for (int var = 0; var < 4; var++) {
         for (int k = 4; k < 6; k++) OK(hipMemset(d[k], 0, n * sizeof(float)));
         float ms = 0;
         for (int rep = 0; rep < 400; rep++) {
@@ -109,6 +156,7 @@ int main() {
             if (var == 0) hipLaunchKernelGGL(k_update<0>, dim3(nb), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy);
             if (var == 1) hipLaunchKernelGGL(k_update<1>, dim3(nb), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy);
             if (var == 2) hipLaunchKernelGGL(k_update<2>, dim3(nb), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy);
+            if (var == 3) hipLaunchKernelGGL(k_update4, dim3(nb4), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx4, gy);
         }
         OK(hipEventRecord(e1, 0));
         OK(hipEventSynchronize(e1));
@@ -119,7 +167,7 @@ int main() {
         OK(hipMemcpy(h.data(), d[5], n * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) cs += 3.0 * h[i];
         printf("variant %d (%s): %.2f us per launch, checksum %.9e\n", var,
-               var == 0 ? "all taps global loads" : var == 1 ? "x-taps by ds_bpermute" : "x-taps by DPP wave shifts", 1e3 * ms / 200.0, cs);
+               var == 0 ? "all taps global loads" : var == 1 ? "x-taps by ds_bpermute" : var == 2 ? "x-taps by DPP wave shifts" : "four columns per lane, 16-byte loads", 1e3 * ms / 200.0, cs);
     }
     return 0;
 }
