@@ -197,6 +197,14 @@ def test_bench_spawns_its_own_ranks():
     one = _run_bench(["--gpus", "1"])
     two = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    for line in (one, two):     # the driver's contract: one JSON line with these keys
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in line, k
+        assert line["unit"] == "Gcell-updates/s" and line["scaling"] == "weak" and line["dtype"] == "f32" and line["vs_baseline"] is None
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        assert "workload" in line["config"] and "model" not in line["config"]
     assert two["config"]["parallelism"] == "shots x2" and two["value"] > 0
     if torch.cuda.device_count() >= 2:
         rc = _run_bench(["--gpus", "2"])
