@@ -9,6 +9,8 @@
 //   variant 2: x-taps through DPP wave shifts (wave_shr / wave_shl, 1 and 2 lanes), edge lanes load
 //   variant 3: FOUR columns per lane (16-byte loads, a wave covers 256 columns): a quarter of the vector-memory instructions,
 //              x-taps mostly from the lane's own registers, 1-2 halo values per lane and array by (cached) loads
+//   variant 4: LDS halo staging of the z-direction: blocks of 8 rows stage their rows of szz / sxz (+ 5 halo rows) in LDS
+//              once, one barrier, every z-tap is an LDS read (the x-taps stay shifted loads)
 // Prints microseconds per launch (mean of the back half of 400 launches) and the checksum of the result (equal for all).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o xtap_probe xtap_probe.hip && ./xtap_probe
 #include <hip/hip_runtime.h>
@@ -129,6 +131,46 @@ __global__ __launch_bounds__(1024) void k_update4(const float *__restrict__ szz,
     *reinterpret_cast<float4 *>(vx + i) = make_float4(ox[0], ox[1], ox[2], ox[3]);
 }
 
+// variant 4: z-taps from an LDS tile of 8 rows + halo rows
+__global__ __launch_bounds__(512) void k_update_lds(const float *__restrict__ szz, const float *__restrict__ sxz, const float *__restrict__ sxx,
+                                                    const float *__restrict__ rho, float *__restrict__ vz, float *__restrict__ vx, int gx, int gy8) {
+    __shared__ float t_zz[11][64], t_xz[11][64];  // rows z0-1 .. z0+9 of szz, rows z0-2 .. z0+8 of sxz
+    int t = blockIdx.x;
+    const int per = (gx * gy8 + 7) >> 3;
+    t = (t & 7) * per + (t >> 3);
+    const int ty = t / gx, tx = t - ty * gx;
+    if (ty >= gy8) return;  // whole block
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int x = tx * 64 + lane, z0 = ty * 8;
+    const int z = __builtin_amdgcn_readfirstlane(z0 + w);
+    auto row = [&](const float *a, int zz) { return (zz >= 0 && zz < NZ + 4) ? a[(size_t)zz * P + x] : 0.0f; };
+    t_zz[w + 1][lane] = row(szz, z);
+    t_xz[w + 2][lane] = row(sxz, z);
+    if (w == 0) { t_zz[0][lane] = row(szz, z0 - 1); t_xz[0][lane] = row(sxz, z0 - 2); }
+    if (w == 1) t_xz[1][lane] = row(sxz, z0 - 1);
+    if (w == 2) t_zz[9][lane] = row(szz, z0 + 8);
+    if (w == 3) t_zz[10][lane] = row(szz, z0 + 9);
+    if (w == 4) t_xz[10][lane] = row(sxz, z0 + 8);
+    const bool on = z >= 2 && z <= NZ - 3 && x >= 2 && x <= NX - 3;
+    const size_t i = (size_t)z * P + x;
+    float sxx_m1 = 0, sxx_0 = 0, sxx_p1 = 0, sxx_p2 = 0, xz_m2 = 0, xz_m1 = 0, xz_p1 = 0, r0 = 1, rz = 1, rx = 1, vz0 = 0, vx0 = 0;
+    if (on) {  // everything that is not a z-tap: issued before the barrier so that it overlaps the staging
+        sxx_m1 = sxx[i - 1]; sxx_0 = sxx[i]; sxx_p1 = sxx[i + 1]; sxx_p2 = sxx[i + 2];
+        xz_m2 = sxz[i - 2]; xz_m1 = sxz[i - 1]; xz_p1 = sxz[i + 1];
+        r0 = rho[i]; rz = rho[i + P]; rx = rho[i + 1];
+        vz0 = vz[i]; vx0 = vx[i];
+    }
+    __syncthreads();
+    if (!on) return;
+    const float dszz_dz = dplus(t_zz[w][lane], t_zz[w + 1][lane], t_zz[w + 2][lane], t_zz[w + 3][lane]);
+    const float dsxz_dz = dminus(t_xz[w][lane], t_xz[w + 1][lane], t_xz[w + 2][lane], t_xz[w + 3][lane]);
+    const float dsxz_dx = dminus(xz_m2, xz_m1, t_xz[w + 2][lane], xz_p1);
+    const float dsxx_dx = dplus(sxx_m1, sxx_0, sxx_p1, sxx_p2);
+    const float ba = 2.0f / (rz + r0), bb = 2.0f / (rx + r0);
+    vz[i] = vz0 + (dszz_dz + dsxz_dx) * ba * 1e-3f;
+    vx[i] = vx0 + (dsxz_dz + dsxx_dx) * bb * 1e-3f;
+}
+
 int main() {
     const size_t n = (size_t)(NZ + 4) * P;
     float *d[6];
@@ -148,7 +190,8 @@ int main() {
     OK(hipEventCreate(&e0));
     OK(hipEventCreate(&e1));
     const int gx4 = (NX + 255) / 256, nb4 = ((gx4 * gy + 7) / 8) * 8;
-    for (int var = 0; var < 4; var++) {
+    const int gy8 = (NZ + 7) / 8, nb8 = ((gx * gy8 + 7) / 8) * 8;
+    for (int var = 0; var < 5; var++) {
         for (int k = 4; k < 6; k++) OK(hipMemset(d[k], 0, n * sizeof(float)));
         float ms = 0;
         for (int rep = 0; rep < 400; rep++) {
@@ -157,6 +200,7 @@ int main() {
             if (var == 1) hipLaunchKernelGGL(k_update<1>, dim3(nb), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy);
             if (var == 2) hipLaunchKernelGGL(k_update<2>, dim3(nb), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy);
             if (var == 3) hipLaunchKernelGGL(k_update4, dim3(nb4), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx4, gy);
+            if (var == 4) hipLaunchKernelGGL(k_update_lds, dim3(nb8), dim3(512), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy8);
         }
         OK(hipEventRecord(e1, 0));
         OK(hipEventSynchronize(e1));
@@ -167,7 +211,7 @@ int main() {
         OK(hipMemcpy(h.data(), d[5], n * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) cs += 3.0 * h[i];
         printf("variant %d (%s): %.2f us per launch, checksum %.9e\n", var,
-               var == 0 ? "all taps global loads" : var == 1 ? "x-taps by ds_bpermute" : var == 2 ? "x-taps by DPP wave shifts" : "four columns per lane, 16-byte loads", 1e3 * ms / 200.0, cs);
+               var == 0 ? "all taps global loads" : var == 1 ? "x-taps by ds_bpermute" : var == 2 ? "x-taps by DPP wave shifts" : var == 3 ? "four columns per lane, 16-byte loads" : "z-taps staged in LDS, 8-row blocks", 1e3 * ms / 200.0, cs);
     }
     return 0;
 }
