@@ -168,3 +168,30 @@ def test_config1_shape_2000x500_forward_only(tmp_path, hip_ops, oracle):
     for k, c in enumerate(("pr", "vx", "vz", "ett")):
         got = ft.read_shot_gather(str(work / "Data"), c, 0, nSt)
         assert P.rel_l2(got, ref[k]) <= 1e-4, (c, P.rel_l2(got, ref[k]))
+
+
+@pytest.mark.timeout(900)
+def test_headline_grid_shot_groups_add_up(tmp_path, hip_ops):
+    """configs[2] schedules its 32 shots in groups of three forward lanes: at the full grid (fewer steps), the gradient of
+    five shots in one call (a full group + a partial one, lanes re-used) equals the sum of the five single-shot gradients,
+    and the per-shot source gradients land in their rows."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nS = 300
+    pb = bench.setup_problem(str(tmp_path), 1000, 2000, nS, 5)
+    ids = torch.arange(5, dtype=torch.int32)
+    lt, mt, dt_ = [t.cuda() for t in pb["lame_true"]]
+    lam, mu, den = [t.cuda() for t in pb["lame_init"]]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, ids, pb["para_fname"])
+    all5 = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    st = hip_ops.stats(pb["para_fname"], 0)
+    assert st["fwd_steps"] == 5 * (nS - 1) and st["bwd_steps"] == 5 * (nS - 1)
+    tot = [0.0, 0.0, 0.0, 0.0]
+    for k in range(5):
+        one = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids[k:k + 1], pb["para_fname"])
+        for j in range(4):
+            tot[j] = tot[j] + one[j].double()
+        assert P.rel_l2(one[4][0].numpy(), all5[4][k].numpy()) <= 1e-6           # gStf row k of the group call
+    assert abs(float(all5[0]) - float(tot[0])) <= 1e-5 * float(tot[0])
+    for j in (1, 2, 3):
+        assert float((all5[j].double() - tot[j]).norm()) <= 1e-5 * float(tot[j].norm())
