@@ -30,6 +30,41 @@ from sepfwi import utils as ft                 # noqa: E402
 from sepfwi.obj_wrapper import PyTorchObjective  # noqa: E402
 
 
+class TimedObjective(PyTorchObjective):
+    """PyTorchObjective.cache with a stop-watch on each phase of one evaluation: float64 vector -> HBM parameters (unpack),
+    the forward chain (parameterisation maps + propagator call + all-reduce; the propagator's own wall clock comes from
+    sepfwi_stats), the autograd chain rule, HBM gradients -> float64 vector (pack).  What is left of an L-BFGS-B iteration is
+    SciPy's own work on the flat vectors."""
+
+    def __init__(self, obj, loss, para_fname, gpu_id):
+        super().__init__(obj, loss)
+        self.para_fname, self.gpu_id = para_fname, gpu_id
+        self.phases = []
+
+    def cache(self, x):
+        tick = time.perf_counter
+        t0 = tick()
+        state = self.unpack_parameters(x)
+        for name, buf in self.obj.named_buffers():
+            state[name] = buf
+        self.obj.load_state_dict(state)
+        self.cached_x = x
+        self.obj.zero_grad()
+        torch.cuda.synchronize()
+        t1 = tick()
+        val = self.loss()
+        self.f = val.item()
+        torch.cuda.synchronize()
+        t2 = tick()
+        val.backward()
+        torch.cuda.synchronize()
+        t3 = tick()
+        self.jac = self.pack_grads()
+        t4 = tick()
+        prop = fwi_ops.stats(self.para_fname, self.gpu_id)["total_ms"] * 1e-3
+        self.phases.append(dict(unpack=t1 - t0, forward=t2 - t1, propagator=prop, chain_rule=t3 - t2, pack=t4 - t3, total=t4 - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shots", type=int, default=6)
@@ -75,7 +110,7 @@ def main():
     else:
         fwi = M.FWI(T(init[0]), T(init[1]), T(init[2]), Stf, opt, Mask=Mask,
                     Vp_bounds=box(true[0]), Vs_bounds=box(true[1]), Den_bounds=box(true[2]))
-    obj = PyTorchObjective(fwi, lambda: fwi(Shot_ids, ngpu=1))
+    obj = TimedObjective(fwi, lambda: fwi(Shot_ids, ngpu=1), pb["para_fname"], local)
     fun, jac = obj.fun, obj.jac
     evals = []
 
@@ -119,6 +154,19 @@ def main():
               "the all-reduce and the host <-> device copies of the flat vectors" %
               (res.nit, len(evals), wall, wall - float(np.sum(evals)), obj.x0.size, hist[0], hist[-1], float(np.mean(evals)),
                upd / float(np.mean(evals)) / 1e9))
+        ph = obj.phases
+        mean = lambda k: float(np.mean([p[k] for p in ph]))
+        ev = mean("total")
+        print("split of one evaluation (mean of %d) [s]: unpack x -> HBM %.3f | forward chain %.3f of which the propagator call "
+              "%.3f (maps, all-reduce, misfit read-back: %.3f) | autograd chain rule %.3f | pack gradients -> float64 %.3f | "
+              "total %.3f" % (len(ph), mean("unpack"), mean("forward"), mean("propagator"), mean("forward") - mean("propagator"),
+                             mean("chain_rule"), mean("pack"), ev))
+        scipy_s = wall - float(np.sum([p["total"] for p in ph]))
+        print("split of the run [s]: %d evaluations %.1f (propagator %.1f = %.1f %%) | SciPy L-BFGS-B on %d float64 unknowns %.1f "
+              "(%.2f per iteration) | wall %.1f  => host share outside the propagator %.1f %%" %
+              (len(ph), float(np.sum([p["total"] for p in ph])), float(np.sum([p["propagator"] for p in ph])),
+               100.0 * float(np.sum([p["propagator"] for p in ph])) / wall, obj.x0.size, scipy_s, scipy_s / max(res.nit, 1), wall,
+               100.0 * (1.0 - float(np.sum([p["propagator"] for p in ph])) / wall)))
     if world > 1:
         import torch.distributed as td
         td.destroy_process_group()
