@@ -248,3 +248,62 @@ def test_headline_32_shot_call_equals_the_sum_of_its_groups(tmp_path, hip_ops):
     dev = [float((all32[j].double() - tot[j]).norm()) / float(tot[j].norm()) for j in (1, 2, 3)]
     print("32-shot call vs the sum of its groups, rel-L2 of gLambda, gMu, gDen:", dev)
     assert max(dev) <= 5e-5, dev
+
+
+HEADLINE_GOLDEN = os.path.join(ROOT, "tests", "golden", "oracle_headline.npz")
+
+
+@pytest.mark.timeout(600)
+def test_headline_full_size_matches_oracle(tmp_path, hip_ops):
+    """BASELINE.json configs[2] ("grad checked vs reference") at its REAL size: one shot of bench.py's 2000 x 1000 problem,
+    4000 time steps, 1980 DAS channels, forward + boundary-saving adjoint, against the CPU oracle's run of the same inputs
+    (scripts/make_golden_headline.py: 35e9 cell-updates on the host, decimated to tests/golden/oracle_headline.npz).
+    The gradient call uses the observed gather this library modelled itself -- the oracle's full gather (32 MB) is not
+    committed; 64 of its channels are, and are compared first.  Tolerances are SURVEY.md 8c's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import scripts.make_golden_headline as mg
+    from sepfwi import utils as ft
+    G = np.load(HEADLINE_GOLDEN)
+    nS = mg.NSTEPS
+    pb = bench.setup_problem(str(tmp_path), mg.NZ, mg.NX, nS, mg.NSHOTS)
+    assert mg.digest(pb) == str(G["digest"]), "bench.py's problem generator drifted: regenerate with scripts/make_golden_headline.py"
+    ids = torch.tensor([mg.SHOT], dtype=torch.int32)
+    lt, mt, dt_ = [t.cuda() for t in pb["lame_true"]]
+    lam, mu, den = [t.cuda() for t in pb["lame_init"]]
+    data_dir = str(tmp_path / "Data")
+    ch, ch8 = G["channels"], G["channels_other"]
+    # observed data of the "true" model: all four components on the committed channels
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, ids, pb["para_fname"])
+    obs = {c: ft.read_shot_gather(data_dir, c, mg.SHOT, nS) for c in ("pr", "vx", "vz", "ett")}
+    assert obs["ett"].shape == (pb["nrec"], nS)
+    dev = {"ett": P.rel_l2(obs["ett"][ch], G["obs_ett"])}
+    for c in ("pr", "vx", "vz"):
+        dev[c] = P.rel_l2(obs[c][ch8], G["obs_" + c])
+    print("observed gather vs oracle (rel-L2 on the committed channels):", dev)
+    assert max(dev.values()) <= 1e-4, dev
+    assert abs(np.linalg.norm(obs["ett"].astype(np.float64)) - float(G["obs_ett_norm"])) <= 1e-4 * float(G["obs_ett_norm"])   # ALL 1980 channels
+    late = slice(3 * nS // 4, nS)                                             # the last 1000 steps on their own
+    assert P.rel_l2(obs["ett"][ch][:, late], G["obs_ett"][:, late]) <= 1e-4
+    # gradient of the initial model
+    m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    e_m = abs(float(m) - float(G["misfit"])) / float(G["misfit"])
+    out = {"misfit": e_m}
+    assert e_m <= 1e-4, (float(m), float(G["misfit"]))
+    d = int(G["decim"])
+    z0, z1, x0, x1 = [int(v) for v in G["win"]]
+    for key, g in (("gLambda", gL), ("gMu", gM), ("gDen", gD)):
+        g = g.cpu().numpy()
+        gmax = float(G[key + "_max"])
+        dec, win = g[::d, ::d], g[z0:z1, x0:x1]
+        out[key] = (P.rel_l2(dec, G[key + "_dec"]), P.rel_l2(win, G[key + "_win"]),
+                    abs(np.linalg.norm(g.astype(np.float64)) - float(G[key + "_norm"])) / float(G[key + "_norm"]))
+        assert out[key][0] <= 1e-3 and out[key][1] <= 1e-3 and out[key][2] <= 1e-3, (key, out[key])
+        assert np.abs(dec - G[key + "_dec"]).max() <= 1e-3 * gmax and np.abs(win - G[key + "_win"]).max() <= 1e-3 * gmax, key
+        assert abs(float(np.abs(g).max()) - gmax) <= 1e-3 * gmax, key
+    out["gStf"] = P.rel_l2(gS.numpy()[0], G["gStf"])
+    assert out["gStf"] <= 1e-3, out
+    print("gradient call vs oracle: misfit rel, (rel-L2 every 8th cell, rel-L2 96x96 window under the source, rel norm) per gradient, gStf:", out)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "headline_vs_oracle.txt"), "w") as fp:
+        fp.write("2000x1000x4000, one shot, HIP path vs CPU oracle (tests/golden/oracle_headline.npz)\nobserved gather rel-L2: %r\ngradient call: %r\n" % (dev, out))
