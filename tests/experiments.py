@@ -90,15 +90,7 @@ def run_iterate0(exp, workdir, ngpu=1, device=None):
     Stf, Mask = su["Stf"].to(dev), su["Mask"].to(dev)
     M.FWI_obscalc(pad(vp_t), pad(vs_t), pad(rho_t), Stf, su["para_fname"])(su["Shot_ids"], ngpu=ngpu)
     T = lambda a: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True)
-    if exp == "001":
-        fwi = M.FWI(T(vp_i), T(vs_i), T(rho_i), Stf, su["opt"], Mask=Mask)
-    elif exp == "002":
-        lam_i = rho_i * (vp_i ** 2 - 2.0 * vs_i ** 2) / 1e6          # Main-002:119-120
-        mu_i = rho_i * vs_i ** 2 / 1e6
-        fwi = M.FWI_Lame_Den(T(lam_i), T(mu_i), T(rho_i), Stf, su["opt"], Mask=Mask)
-    else:
-        vpk, vsk = vp_i / 1e3, vs_i / 1e3                              # Main-003:119-122
-        fwi = M.FWI_IP_IS_Den(T(vpk * rho_i), T(vsk * rho_i), T(rho_i), Stf, su["opt"], Mask=Mask)
+    fwi = _module_for(exp, su, (vp_i, vs_i, rho_i), T, Stf, Mask)
     obj = PyTorchObjective(fwi, lambda: fwi(su["Shot_ids"], ngpu=ngpu))
     jac = obj.jac            # the reference's quirk: cache() shadows .jac with the array (obj_wrapper.py:86)
     f = obj.fun(obj.x0)
@@ -107,26 +99,45 @@ def run_iterate0(exp, workdir, ngpu=1, device=None):
     return dict(f=f, ginf=float(np.abs(g).max()), grads=grads, N=int(obj.x0.size))
 
 
-def run_lbfgs(exp, workdir, nIter=3, ngpu=1):
+def _module_for(exp, su, models_i, T, Stf, Mask):
+    """The reference's nn.Module of the experiment at its initial model (Main-00{1,2,3}-...py:116-124)."""
+    from sepfwi import modules as M
+    vp_i, vs_i, rho_i = models_i
+    if exp == "001":
+        return M.FWI(T(vp_i), T(vs_i), T(rho_i), Stf, su["opt"], Mask=Mask)
+    if exp == "002":
+        lam_i = rho_i * (vp_i ** 2 - 2.0 * vs_i ** 2) / 1e6          # Main-002:119-120
+        mu_i = rho_i * vs_i ** 2 / 1e6
+        return M.FWI_Lame_Den(T(lam_i), T(mu_i), T(rho_i), Stf, su["opt"], Mask=Mask)
+    vpk, vsk = vp_i / 1e3, vs_i / 1e3                                  # Main-003:119-122
+    return M.FWI_IP_IS_Den(T(vpk * rho_i), T(vsk * rho_i), T(rho_i), Stf, su["opt"], Mask=Mask)
+
+
+def run_lbfgs(exp, workdir, nIter=3, ngpu=1, with_projg=False):
     """The reference's inversion driver, unchanged in structure (Main-001-...py:126-168): SciPy L-BFGS-B with the
-    reference's options on top of PyTorchObjective.  Returns the list of misfits at the accepted iterates."""
+    reference's options on top of PyTorchObjective.  Returns the list of misfits at the accepted iterates (and, with
+    with_projg, the gradient inf-norms there: what the L-BFGS-B log prints as |proj g| for an unconstrained problem)."""
     from scipy import optimize
     from sepfwi import modules as M
     from sepfwi import utils as ft
     from sepfwi.obj_wrapper import PyTorchObjective
-    assert exp == "001"
     su = setup(exp, workdir)
-    (vp_t, vs_t, rho_t), (vp_i, vs_i, rho_i) = models(exp)
+    (vp_t, vs_t, rho_t), models_i = models(exp)
     pad = lambda a: torch.tensor(ft.padding_numpy_array(a, nPml, su["nPad"]), dtype=torch.float32)
     M.FWI_obscalc(pad(vp_t), pad(vs_t), pad(rho_t), su["Stf"], su["para_fname"])(su["Shot_ids"], ngpu=ngpu)
     T = lambda a: torch.tensor(a, dtype=torch.float32, requires_grad=True)
-    fwi = M.FWI(T(vp_i), T(vs_i), T(rho_i), su["Stf"], su["opt"], Mask=su["Mask"])
+    fwi = _module_for(exp, su, models_i, T, su["Stf"], su["Mask"])
     obj = PyTorchObjective(fwi, lambda: fwi(su["Shot_ids"], ngpu=ngpu))
-    hist = []
+    hist, projg = [], []
     fun, jac = obj.fun, obj.jac
     f0 = fun(obj.x0)
     hist.append(f0)
-    optimize.minimize(fun, obj.x0, method="L-BFGS-B", jac=jac, bounds=obj.bounds, tol=None,
-                      callback=lambda x: hist.append(obj.f),
+    projg.append(float(np.abs(jac(obj.x0)).max()))
+
+    def cb(x):
+        hist.append(fun(x))                      # cached: the line search ended at x
+        projg.append(float(np.abs(jac(x)).max()))
+
+    optimize.minimize(fun, obj.x0, method="L-BFGS-B", jac=jac, bounds=obj.bounds, tol=None, callback=cb,
                       options={"gtol": 1e-16, "maxiter": nIter, "ftol": 1e-12, "maxcor": 5, "maxfun": 1500, "maxls": 6})
-    return hist
+    return (hist, projg) if with_projg else hist
