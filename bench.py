@@ -76,11 +76,13 @@ def setup_problem(workdir, nz, nx, nSteps, n_shots_total, nPml=32, dh=10.0, dt=1
                 nz_pad=nz_pad, nx_pad=nx_pad, n_c=(nz + 2 * nPml) * nx_pad, nrec=int(rec_x.size))
 
 
-def cpu_baseline(nz, nx, seconds=15.0):
+def cpu_baseline(nz, nx, seconds=12.0):
     """The reference's CPU propagator is the Numba solver (DAS_Waveform_Modeling/src/elasticSolver.py);
     numba cannot travel, so its C restatement (oracle/numba_oracle.c, pinned bit-for-bit to the reference
     by tests/golden/numba_*.npz) is timed: one shot per host core, like Pool(min(nsrc, cpu_count))
-    (elasticSolver.py:163-166), on the SAME 2000x1000 grid for a bounded number of steps."""
+    (elasticSolver.py:163-166), on the SAME 2000x1000 grid for a bounded number of steps -> `value`.  Extra keys
+    (BASELINE.md section 3): the same solver on ONE core, and the float32 restatement of the TorchFWI fwd+adj path (the
+    parity oracle, oracle/torchfwi_oracle.c) with one shot per core -- the like-for-like figure of the GPU metric."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build()
@@ -99,17 +101,79 @@ def cpu_baseline(nz, nx, seconds=15.0):
         return time.perf_counter() - t0
 
     t_probe = run(4)
-    nt = int(max(4, min(400, seconds / max(t_probe / 4.0, 1e-6))))
+    nt1 = int(max(4, min(400, 0.4 * seconds / max(t_probe / 4.0, 1e-6))))
+    t_one = run(nt1)                                        # one shot on one core, nothing else running
+    cells = (nx + 2 * ndamp) * (nz + 2 * ndamp)
+    one_core = cells * nt1 / t_one / 1e9
+    nt = int(max(4, min(400, seconds / max(t_one / nt1, 1e-6))))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(lambda _: run(nt), range(cores)))
     el = time.perf_counter() - t0
-    cells = (nx + 2 * ndamp) * (nz + 2 * ndamp)
     val = cores * cells * nt / el / 1e9
-    return {"value": round(val, 5), "unit": "Gcell-updates/s", "cores": cores, "kind": "port",
-            "sample": "float64 C restatement of elasticSolver.py (velocity+stress = 1 cell-update), %dx%d grid + %d sponge, "
-                      "%d steps, %d shots in parallel (one per core; os.cpu_count() = %d, capped at 32), forward only, %.1f s"
-                      % (nx, nz, ndamp, nt, cores, host_cores, el)}
+    out = {"value": round(val, 5), "unit": "Gcell-updates/s", "cores": cores, "kind": "port",
+           "sample": "float64 C restatement of elasticSolver.py (velocity+stress = 1 cell-update), %dx%d grid + %d sponge, "
+                     "%d steps, %d shots in parallel (one per core; os.cpu_count() = %d, capped at 32), forward only, %.1f s"
+                     % (nx, nz, ndamp, nt, cores, host_cores, el),
+           "one_core": {"value": round(one_core, 5), "unit": "Gcell-updates/s", "cores": 1,
+                        "sample": "the same solver, one shot on one core, %d steps, %.1f s" % (nt1, t_one)}}
+    try:
+        out["torchfwi_f32_fwdadj"] = cpu_baseline_fwdadj(nz, nx, cores, seconds)
+    except Exception as e:      # a reported extra: never let it take the bench line down
+        out["torchfwi_f32_fwdadj"] = {"error": repr(e)[:200]}
+    return out
+
+
+def cpu_baseline_fwdadj(nz, nx, cores, seconds):
+    """The float32 CPU restatement of the TorchFWI propagator (the parity oracle) on the bench problem's own padded grid:
+    forward + boundary-saving adjoint of `cores` shots, one per core (its OpenMP loop over shots), for a bounded number of
+    time steps.  Same cell-update count as the GPU metric: 3 * N_c * (nSteps - 1) per shot."""
+    from oracle import oracle as O
+    from sepfwi import utils as ft
+    import json
+    nPml = 32
+    nPad = ft.nPad_for(nz, nPml)
+    nz_pad, nx_pad = nz + 2 * nPml + nPad, nx + 2 * nPml
+    n_c = (nz + 2 * nPml) * nx_pad
+    lam = np.full((nz_pad, nx_pad), 2400.0 * (3000.0 ** 2 - 2.0 * 1732.0 ** 2) / 1e6, np.float32)
+    mu = np.full((nz_pad, nx_pad), 2400.0 * 1732.0 ** 2 / 1e6, np.float32)
+    den = np.full((nz_pad, nx_pad), 2400.0, np.float32)
+
+    def run(nt, nshots):
+        d = tempfile.mkdtemp(prefix="sepfwi_cpu_")
+        try:
+            pf, sf = os.path.join(d, "p.json"), os.path.join(d, "s.json")
+            ft.paraGen(nz_pad, nx_pad, 10.0, 10.0, nt, 1.0e-3, 10.0, nPml, nPad, pf, sf, os.path.join(d, "Data"))
+            rx = np.arange(10, nx - 10).astype(int)
+            sx = np.linspace(10, nx - 11, nshots).round().astype(int)
+            ft.surveyGen(np.full(sx.shape, 2), sx, np.full(rx.shape, 2), rx, sf)
+            para, survey = json.load(open(pf)), json.load(open(sf))
+            stf = np.tile(ft.sourceGene(10.0, nt, 1.0e-3).astype(np.float32), (nshots, 1))
+            obs = np.zeros((nshots, 4, rx.size, nt), np.float32)
+            t0 = time.perf_counter()
+            O.cufd(lam, mu, den, stf, 1, list(range(nshots)), para, survey, obs=obs)
+            return time.perf_counter() - t0
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    t_probe = run(6, cores)       # the oracle's OpenMP loop over shots: one shot per thread, `cores` shots -> `cores` threads busy
+    nt = int(max(6, min(200, 1 + seconds / max(t_probe / 5.0, 1e-6))))
+    el = run(nt, cores)
+    val = cores * 3.0 * n_c * (nt - 1) / el / 1e9
+    return {"value": round(val, 5), "unit": "Gcell-updates/s (fwd+adj)", "cores": cores, "kind": "port",
+            "sample": "float32 C restatement of the reference's cufd (forward + boundary-saving adjoint + imaging), padded %dx%d "
+                      "grid, %d time steps, %d shots in parallel (one per core), %.1f s" % (nx_pad, nz_pad, nt, cores, el)}
+
+
+def kernel_source_digest():
+    """sha256 over the files that define the field kernels: profiles/traffic.json carries the digest of the version its PMC
+    counters were collected on (scripts/make_traffic_json.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "device_common.hpp", "fwi_types.hpp"):
+        with open(os.path.join(ROOT, "sep-2023_amd", "csrc", f), "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()
 
 
 def launcher_cmd(n_gpus, argv, port=None):
@@ -142,11 +206,10 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # bare `python bench.py --gpus N`: nothing has touched the GPU yet, so become the launcher of N ranks (child
-        # process; its exit code is ours) instead of silently measuring one GPU
+        # bare `python bench.py --gpus N`: become the launcher of N ranks (a child process; its exit code is ours) instead of
+        # silently measuring one GPU.  This parent never initialises the HIP runtime.
         import subprocess
-        if not args.share_gpu and torch.cuda.device_count() < args.gpus:
-            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
+        # (the parent stays GPU-free: no device query here -- a rank without a device fails with its own message below)
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(launcher_cmd(args.gpus, sys.argv[1:]), env=env))
@@ -160,6 +223,8 @@ def main():
         local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if local >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d needs HIP device %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
@@ -245,7 +310,10 @@ def main():
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
             if os.path.exists(tf) and args.nz == 1000 and args.nx == 2000:
-                traffic = json.load(open(tf)).get("k_bwd_b_bytes_per_launch")
+                tj = json.load(open(tf))
+                # the counters were collected on ONE version of the kernels: a changed kernel file makes them stale -> null
+                if tj.get("kernel_source_sha256") == kernel_source_digest():
+                    traffic = tj.get("k_bwd_b_bytes_per_launch")
             if args.mode == "fwdadj" and probe_n > 0:
                 per_step_us = probe_us / probe_n
                 ach = pb["n_c"] * BYTES_K_BWD_STRESS / (per_step_us * 1e-6) / 1e9

@@ -123,7 +123,7 @@ typedef struct sepfwi_stats {
     long long launches;       /* kernel launches issued                                       */
     long long device_bytes;   /* device memory held by the session                            */
     int n_c;                  /* computed cells per step (nz-nPad)*(nx)  [PML included]       */
-    double probe_kernel_us;   /* option "probe">0: mean duration of the sampled k_bwd_stress launches   */
+    double probe_kernel_us;   /* option "probe">0: mean duration of the sampled k_bwd_b launches (HIP events) */
     long long probe_calls;    /* number of sampled launches                                     */
 } sepfwi_stats;
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);

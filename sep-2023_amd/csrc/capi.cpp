@@ -135,6 +135,14 @@ int sepfwi_debug_field(const char *para_fname, int gpu_id, int lane, int which, 
     });
 }
 
+// The calling thread's current HIP device, restored on scope exit: the parameterisation maps run on the autograd thread, whose
+// current device torch's own guards read back with hipGetDevice.
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // every pointer of the fused parameterisation maps must be device memory of ONE device (the maps run where the tensors live)
 static int common_device(std::initializer_list<const void *> ptrs) {
     int dev = -1;
@@ -161,6 +169,7 @@ int sepfwi_param_forward(int kind, int nz, int nx, int nPml, int nPad, const flo
     return guarded([&] {
         check_param_dims(kind, nz, nx, nPml, nPad);
         const int dev = common_device({A, B, C, A_ref, B_ref, C_ref, Mask, Lambda, Mu, Den});
+        DeviceRestore restore;
         if (hipSetDevice(dev) != hipSuccess) throw HipError("hipSetDevice failed");
         launch_param_fwd((hipStream_t)hip_stream, kind, nz, nx, nPml, nPad, A, B, C, A_ref, B_ref, C_ref, Mask, Lambda, Mu, Den);
         if (hipGetLastError() != hipSuccess) throw HipError("param map launch failed");
@@ -173,6 +182,7 @@ int sepfwi_param_backward(int kind, int nz, int nx, int nPml, int nPad, const fl
     return guarded([&] {
         check_param_dims(kind, nz, nx, nPml, nPad);
         const int dev = common_device({A, B, C, A_ref, B_ref, C_ref, Mask, gLambda, gMu, gDen, gA, gB, gC});
+        DeviceRestore restore;
         if (hipSetDevice(dev) != hipSuccess) throw HipError("hipSetDevice failed");
         launch_param_bwd((hipStream_t)hip_stream, kind, nz, nx, nPml, nPad, A, B, C, A_ref, B_ref, C_ref, Mask, gLambda, gMu, gDen, gA,
                          gB, gC);

@@ -41,26 +41,49 @@ def my_block(n_shots: int):
     return b[rank()], b[rank() + 1]
 
 
-def allreduce_gradients(misfit, gL, gM, gD):
-    """Sum [gLambda | gMu | gDen | misfit] over ranks with ONE collective.  Tensors may live on the
-    host (gloo) or on the rank's GPU (RCCL); results come back in place, same shapes."""
+def fused_view(misfit, gL, gM, gD):
+    """The 1-D tensor [gLambda | gMu | gDen | misfit] when the four already ARE one contiguous buffer in that order
+    (ops._cufd allocates them that way and the session writes gradients and misfit straight into it), else None."""
     n = gL.numel()
-    dev = gL.device
+    try:
+        base = gL.untyped_storage().data_ptr()
+        same = all(t.untyped_storage().data_ptr() == base and t.device == gL.device and t.dtype == torch.float32 and t.is_contiguous()
+                   for t in (gM, gD, misfit))
+    except RuntimeError:
+        return None
+    o = gL.storage_offset()
+    if not (same and gL.is_contiguous() and gM.numel() == n and gD.numel() == n and misfit.numel() == 1 and
+            gM.storage_offset() == o + n and gD.storage_offset() == o + 2 * n and misfit.storage_offset() == o + 3 * n):
+        return None
+    return torch.as_strided(gL, (3 * n + 1,), (1,), o)
+
+
+def allreduce_gradients(misfit, gL, gM, gD):
+    """Sum [gLambda | gMu | gDen | misfit] over ranks with ONE collective, in place.  On the production path (RCCL, model in
+    HBM) the four tensors are views of the one buffer the session wrote, which is handed to all_reduce as it is: no staging
+    copy, the misfit never leaves the device.  Other combinations (gloo with HIP tensors: ranks sharing a GPU in rehearsals;
+    RCCL with the reference's CPU tensors; tensors that are not one buffer) stage ONE fused copy each way."""
+    n = gL.numel()
     backend = td.get_backend()
-    if backend == "nccl":     # RCCL reduces device buffers
-        use_dev = dev if dev.type == "cuda" else torch.device("cuda", local_device_index())
-    else:                     # gloo (CPU tests, or several ranks sharing one GPU): reduce on the host
-        use_dev = torch.device("cpu")
-    fused = torch.empty(3 * n + 1, dtype=torch.float32, device=use_dev)
-    fused[0:n] = gL.reshape(-1).to(use_dev)
-    fused[n:2 * n] = gM.reshape(-1).to(use_dev)
-    fused[2 * n:3 * n] = gD.reshape(-1).to(use_dev)
-    fused[3 * n] = misfit.reshape(-1)[0].to(use_dev)
-    td.all_reduce(fused, op=td.ReduceOp.SUM)
-    gL.copy_(fused[0:n].view_as(gL))
-    gM.copy_(fused[n:2 * n].view_as(gM))
-    gD.copy_(fused[2 * n:3 * n].view_as(gD))
-    misfit = fused[3 * n:3 * n + 1].to(misfit.device).clone()
+    want = "cuda" if backend == "nccl" else "cpu"     # RCCL reduces device buffers, gloo host buffers
+    fused = fused_view(misfit, gL, gM, gD)
+    if fused is not None and fused.device.type == want:
+        td.all_reduce(fused, op=td.ReduceOp.SUM)
+        return misfit, gL, gM, gD
+    use_dev = torch.device("cuda", local_device_index()) if want == "cuda" else torch.device("cpu")
+    if want == "cuda" and gL.is_cuda:
+        use_dev = gL.device
+    if fused is not None:
+        stage = fused.to(use_dev)
+        td.all_reduce(stage, op=td.ReduceOp.SUM)
+        fused.copy_(stage)
+        return misfit, gL, gM, gD
+    stage = torch.cat([gL.reshape(-1).to(use_dev), gM.reshape(-1).to(use_dev), gD.reshape(-1).to(use_dev), misfit.reshape(-1)[:1].to(use_dev)])
+    td.all_reduce(stage, op=td.ReduceOp.SUM)
+    gL.copy_(stage[0:n].view_as(gL))
+    gM.copy_(stage[n:2 * n].view_as(gM))
+    gD.copy_(stage[2 * n:3 * n].view_as(gD))
+    misfit = stage[3 * n:3 * n + 1].to(misfit.device).clone()
     return misfit, gL, gM, gD
 
 

@@ -102,10 +102,17 @@ class _MaskedTriple(nn.Module):
         raise NotImplementedError
 
     def _fusable(self):
+        """The one-launch maps take raw pointers and the sizes of the module: every tensor must have exactly the shape the
+        kernels index (a Mask that torch would broadcast, or a parameter of another shape, stays on the torch expressions,
+        which broadcast or raise)."""
         cur = [getattr(self, n) for n in self.NAMES]
+        refs = [getattr(self, n + "_ref") for n in self.NAMES]
+        padded_shape = (self.nz + 2 * self.nPml + self.nPad, self.nx + 2 * self.nPml)
         return (USE_FUSED_MAPS and self.KIND is not None and self.nz == self.nz_orig and self.nx == self.nx_orig
-                and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.device == self.Mask.device for t in cur)
-                and self.Mask.dtype == torch.float32)
+                and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.device == self.Mask.device
+                        and tuple(t.shape) == (self.nz_orig, self.nx_orig) for t in cur)
+                and all(tuple(t.shape) == padded_shape and t.dtype == torch.float32 and t.device == self.Mask.device for t in refs)
+                and self.Mask.dtype == torch.float32 and tuple(self.Mask.shape) == padded_shape)
 
     def lame_padded(self):
         """-> Lambda [MPa], Mu [MPa], Den on the padded grid, differentiable w.r.t. the module's parameters."""

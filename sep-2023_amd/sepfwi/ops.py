@@ -93,9 +93,12 @@ class _FwiOps:
         misfit = torch.zeros(1, dtype=torch.float32)
         gL = gM = gD = gS = None
         if calc_id == 1:
-            gL = torch.zeros(Lambda.shape, dtype=torch.float32, device=gdev)
-            gM = torch.zeros_like(gL)
-            gD = torch.zeros_like(gL)
+            # ONE buffer [gLambda | gMu | gDen | misfit]: the session writes all four in place, and under torch.distributed
+            # this very buffer is what the single all-reduce sums (dist.allreduce_gradients) -- no staging, misfit stays in HBM
+            n = Lambda.numel()
+            fused = torch.zeros(3 * n + 1, dtype=torch.float32, device=gdev)
+            gL, gM, gD = (fused[k * n:(k + 1) * n].view(Lambda.shape) for k in range(3))
+            misfit = fused[3 * n:3 * n + 1]
             gS = torch.zeros((int(ids.size), Stf.shape[1]), dtype=torch.float32)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         stream = None        # NULL = the legacy default stream: the library orders itself behind it
@@ -115,15 +118,15 @@ class _FwiOps:
         return misfit, gL, gM, gD, gS
 
     def _device_for(self, t: torch.Tensor, i: int, ngpu: int = 1) -> int:
-        """HIP device of shot block `i` of `ngpu`: the pinned one (bench, tests), this rank's under torch.distributed,
-        the tensor's own device for a single block, device i otherwise (the reference's omp thread i <-> GPU i,
-        Src/Torch_Fwi.cpp:71-95)."""
+        """HIP device of shot block `i` of `ngpu`: the pinned one (bench, tests); the tensors' own device for a single block or a
+        rank of a torch.distributed job; LOCAL_RANK for a rank that holds the reference's CPU tensors; device i otherwise (the
+        reference's omp thread i <-> GPU i, Src/Torch_Fwi.cpp:71-95)."""
         if self.device_override is not None:
             return int(self.device_override)
+        if t.is_cuda and (ngpu == 1 or _dist.active()):
+            return t.device.index or 0      # the tensors' own device, also under per-rank device masking (every rank sees one GPU)
         if _dist.active():
             return _dist.local_device_index()
-        if ngpu == 1 and t.is_cuda:
-            return t.device.index or 0
         return i
 
     # -- reference surface -------------------------------------------------------------------
@@ -192,6 +195,8 @@ class _FwiOps:
         ett = _f32c(ett, "ett")
         if ett.dim() != 2:
             raise ValueError("ett must be (nrec, nSteps)")
+        if ett.is_cuda:     # the library copies on its own stream, ordered only behind the legacy default stream
+            torch.cuda.current_stream(ett.device).synchronize()
         dev = self.device_override if self.device_override is not None else int(gpu_id)
         _native.check(_native.lib().sepfwi_set_observed(str(para_fname).encode(), dev, int(shot_id), C.c_void_p(ett.data_ptr()),
                                                         int(ett.shape[0]), int(ett.shape[1])))

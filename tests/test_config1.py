@@ -13,7 +13,10 @@ import torch
 import problems as P
 from conftest import GOLDEN
 
-TOL = 2e-3
+# float32 C-PML scheme vs the reference's float64 sponge scheme before boundary effects matter.  Measured (oracle and HIP path
+# alike): vx, vz, pressure 9.7e-6, axial strain 9.7e-5 (a difference of neighbouring float32 velocities); SURVEY.md 8c
+# proposed <= 1e-4.
+TOL = {"vx": 5e-5, "vz": 5e-5, "pr": 5e-5, "ett": 3e-4}
 NT_CMP = 400
 
 
@@ -46,7 +49,8 @@ def _check(c, syn):
                            ("ett", syn["ett"][:, :k], g["exx"][:, :k] * c["dh"] * fac),
                            ("pr", syn["pr"][:, 1:k + 1], 2.0 * g["pr"][:, :k] * fac)):
         e = P.rel_l2(got, ref)
-        assert e <= TOL, (name, e)
+        print("config 1, %s: rel-L2 %.2e" % (name, e))
+        assert e <= TOL[name], (name, e)
 
 
 def test_config1_oracle_vs_reference_numba_solver(tmp_path, oracle):

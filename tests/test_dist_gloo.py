@@ -56,7 +56,25 @@ def _worker(rank, world, port, q):
     Stf = torch.zeros(7, 11)
     ids = torch.arange(7, dtype=torch.int32)
     m, gL, gM, gD, gS = fwi_ops.backward(lam, lam, lam, Stf, world, ids, "unused.json")
-    q.put((rank, seen, float(m), gL.numpy(), gM.numpy(), gD.numpy(), gS.numpy(), ncoll[0], dist.my_block(7)))
+    first = (rank, seen[:], float(m), gL.numpy().copy(), gM.numpy().copy(), gD.numpy().copy(), gS.numpy().copy(), ncoll[0], dist.my_block(7))
+
+    # the production layout: ops._cufd hands out views of ONE buffer [gL | gM | gD | misfit]; the collective must act on
+    # that buffer itself (no staging copy), still exactly once
+    bufs = []
+
+    def fused_cufd(calc_id, gpu_id, Lambda, Mu, Den, Stf, shot_ids, para_fname, out_device=None):
+        m0, a, b, c, gS0 = fake_cufd(calc_id, gpu_id, Lambda, Mu, Den, Stf, shot_ids, para_fname)
+        n = Lambda.numel()
+        fused = torch.cat([a.reshape(-1), b.reshape(-1), c.reshape(-1), m0.reshape(-1)])
+        bufs.append(fused)
+        return fused[3 * n:3 * n + 1], fused[0:n].view(Lambda.shape), fused[n:2 * n].view(Lambda.shape), fused[2 * n:3 * n].view(Lambda.shape), gS0
+    fwi_ops._cufd = fused_cufd
+    ncoll[0] = 0
+    m2, gL2, gM2, gD2, gS2 = fwi_ops.backward(lam, lam, lam, Stf, world, ids, "unused.json")
+    zero_copy = (dist.fused_view(m2, gL2, gM2, gD2) is not None and gL2.untyped_storage().data_ptr() == bufs[0].untyped_storage().data_ptr()
+                 and ncoll[0] == 1 and torch.equal(gL2, torch.from_numpy(first[3])) and torch.equal(gD2, torch.from_numpy(first[5]))
+                 and float(m2) == first[2])
+    q.put(first + (zero_copy,))
     td.destroy_process_group()
 
 
@@ -79,6 +97,7 @@ def test_two_ranks_partition_and_single_allreduce():
     eD = sum(_shot_grad((6, 5), s)[2] for s in range(7)).numpy()
     for r in res:
         assert r[7] == 1                                    # exactly one collective per operator call
+        assert r[9]                                         # fused buffer reduced in place: same storage, same numbers, one collective
         assert abs(r[2] - (21 + 3.5)) < 1e-5                # misfit summed over ranks
         np.testing.assert_allclose(r[3], eL, rtol=1e-6)
         np.testing.assert_allclose(r[4], eM, rtol=1e-6)
