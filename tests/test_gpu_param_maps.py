@@ -111,3 +111,68 @@ def test_fused_maps_at_headline_size_and_timing(hip_ops):
     dev = [float((a - b).abs().max()) / float(b.abs().max()) for a, b in zip(grads[True], grads[False])]
     print("max deviation fused vs torch ops, relative to the largest gradient entry:", dev)
     assert max(dev) <= 1e-4
+
+
+@pytest.mark.parametrize("cls_name,key", [("FWI_Rock_Physics_VRH", "vrh"), ("FWI_Rock_Physics_gassmann", "gas")])
+def test_rock_physics_modules_on_hip_tensors(tmp_path, hip_ops, cls_name, key):
+    """SURVEY.md 8f-1 remainder: the two rock-physics parameterisations (FWI_ops.py:401-619) with every tensor in HBM.
+    (i) Their (phi, cc, sw) -> Lambda, Mu, Den maps on HIP tensors against the golden vectors generated by importing the
+    reference's fwi_utils.py (tests/golden/rock_physics.npz), float32 accuracy.  (ii) A whole iteration -- module ->
+    FWIFunction -> HIP propagator -> autograd chain rule -- on HIP tensors against the same chain on the reference's CPU
+    tensors: misfit within 1e-5; d/d(phi, cc, sw) of both against the float64 chain rule (<= 5e-4).  They stay torch expressions (about 40 elementwise kernels): the
+    1-GPU end-to-end run (profiles/r03_e2e_1gpu.log) puts the whole parameterisation chain at 0.2 % of an evaluation."""
+    import os
+    from conftest import GOLDEN
+    from sepfwi import modules as M
+    G = np.load(os.path.join(GOLDEN, "rock_physics.npz"))
+    cls = getattr(M, cls_name)
+    phi, cc, sw = [torch.tensor(G[k].astype(np.float32), device="cuda") for k in ("phi", "cc", "sw")]
+    lam, mu, den = cls.lame(None, phi, cc, sw)
+    vp, vs, rho = G[key + "_vp"], G[key + "_vs"], G[key + "_rho"]
+    assert lam.is_cuda and mu.is_cuda and den.is_cuda
+    np.testing.assert_allclose(den.cpu().numpy(), rho, rtol=2e-6)
+    np.testing.assert_allclose(mu.cpu().numpy(), rho * vs ** 2 / 1e6, rtol=2e-5)
+    np.testing.assert_allclose(lam.cpu().numpy(), rho * (vp ** 2 - 2 * vs ** 2) / 1e6, rtol=2e-4)   # a difference of two large moduli in float32
+
+    # whole iteration: smooth rock-property fields on the test grid, observed data from a perturbed set
+    pb = P.make_problem(str(tmp_path), nz=44, nx=60, nPml=10, nSteps=200, nshots=2, hetero=True)
+    rng = np.random.default_rng(5)
+    f0 = [P.smooth_random(rng, (44, 60), lo, hi).astype(np.float32) for lo, hi in ((0.10, 0.30), (0.05, 0.45), (0.2, 0.9))]
+    f1 = [a.copy() for a in f0]
+    f1[0][18:26, 20:30] *= 1.08
+    f1[2][24:32, 35:45] *= 0.9
+    from sepfwi import utils as ft
+    pad = lambda a: torch.tensor(ft.padding_numpy_array(a, pb["nPml"], pb["nPad"]))
+    lam_t, mu_t, den_t = cls.lame(None, *[pad(a) for a in f1])
+    hip_ops.obscalc(lam_t.contiguous(), mu_t.contiguous(), den_t.contiguous(), pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    mask = torch.zeros(pb["nz_pad"], pb["nx_pad"])
+    mask[pb["nPml"] + 3:pb["nPml"] + 44, pb["nPml"]:pb["nPml"] + 60] = 1.0
+    res = {}
+    for dev in ("cuda", "cpu"):
+        prm = [torch.tensor(a, device=dev, requires_grad=True) for a in f0]
+        fwi = cls(prm[0], prm[1], prm[2], pb["Stf"], pb["opt"], Mask=mask.to(dev))
+        loss = fwi(pb["Shot_ids"], ngpu=1)
+        loss.backward()
+        assert all(p.grad.device.type == dev for p in fwi.parameters())
+        res[dev] = [float(loss.detach())] + [p.grad.cpu().numpy() for p in fwi.parameters()]
+    assert res["cpu"][0] > 0
+    assert abs(res["cuda"][0] - res["cpu"][0]) <= 1e-5 * res["cpu"][0], (res["cuda"][0], res["cpu"][0])
+    # yardstick: the same chain rule in float64 (the raw float32 gradients of the propagator pulled back through a float64 copy
+    # of the map).  torch's CPU and GPU float32 kernels round these cancellation-prone expressions differently (the Gassmann
+    # map takes square roots and squares them again): each is compared with the float64 result, not with the other.
+    p32 = [torch.tensor(a, requires_grad=True) for a in f0]
+    m32 = cls(p32[0], p32[1], p32[2], pb["Stf"], pb["opt"], Mask=mask)
+    raw = hip_ops.backward(*[t.detach().contiguous() for t in m32.lame_padded()], pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    p64 = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in f0]
+    m64 = cls(p64[0], p64[1], p64[2], pb["Stf"], pb["opt"], Mask=mask.double())
+    l64, u64, d64 = m64.lame_padded()
+    ((l64 * raw[1].double()).sum() + (u64 * raw[2].double()).sum() + (d64 * raw[3].double()).sum()).backward()
+    for k, name in enumerate(("PHI", "CC", "SW")):
+        ref = list(m64.parameters())[k].grad.numpy()
+        assert np.abs(ref).max() > 0
+        dev = {d: float(np.abs(res[d][1 + k] - ref).max() / np.abs(ref).max()) for d in ("cuda", "cpu")}
+        print("%s d/d%s: float32 chain vs float64 chain rule, max deviation / max |g|: %r" % (cls_name, name, dev))
+        assert dev["cuda"] <= 5e-4 and dev["cpu"] <= 5e-4, (cls_name, name, dev)
+        # (the yardstick uses the CPU run's media, so "cpu" shows the chain rule's own rounding, ~1e-7; torch's GPU kernels
+        # produce media that differ in the last bit, and the propagator's gradient answers a 1-ulp change of the medium with
+        # ~1e-5: measured 2.6e-5 (VRH) and 2e-4 (Gassmann) -- float32 conditioning of the problem, on either device)
