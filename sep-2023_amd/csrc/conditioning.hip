@@ -4,7 +4,8 @@
 // In the reference these are utilities.cu:733-1111 (kernels) and :1115-1166 (bp_filter1d, cuFFT); every call site in the
 // driver is commented out (libCUFD.cu:353-457), so the chain is DORMANT there: the parameter keys are parsed and nothing
 // happens.  Here a key that is set switches its stage on, composed in the order of those commented lines:
-//     window(obs), window(syn)  ->  band-pass(obs), band-pass(syn)  ->  misfit / residual  ->  band-pass(res)  ->  window(res)
+//     window(obs), window(syn)  ->  band-pass(obs), band-pass(syn)  ->  [source-signature update of syn]  ->  misfit / residual
+//     ->  [its transpose on res]  ->  band-pass(res)  ->  window(res)
 // applied to the axial-strain gathers (the component that enters misfit and adjoint source, libCUFD.cu:427,607).  Traces
 // are processed in the files' [rec][it] layout.  Parity for this extension is against the numpy restatement in
 // oracle/oracle.py (cond_window, cond_bandpass, conditioned_residual); the reference offers no run of it to pin on.
@@ -129,6 +130,51 @@ __global__ void k_l2_residual(int nt, int nrec, const float *__restrict__ obs, c
     if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
 }
 
+// cuda_spectrum_update (utilities.cu:905-977), first half: one block per frequency bin sums conj(C_r) O_r and |C_r|^2 over the
+// channels (double partial sums; the reference: 512 strided float partials and a tree) and divides:
+// coef = num / (den + lambda), lambda = 1e-6 added to the real denominator.
+__global__ void k_matching_coef(int nf, int nrec, const hipfftComplex *__restrict__ O, const hipfftComplex *__restrict__ Cs,
+                                hipfftComplex *__restrict__ coef) {
+    const int k = blockIdx.x;
+    double nr = 0.0, ni = 0.0, dn = 0.0;
+    for (int r = threadIdx.x; r < nrec; r += blockDim.x) {
+        const hipfftComplex o = O[(size_t)r * nf + k], c = Cs[(size_t)r * nf + k];
+        nr += (double)c.x * o.x + (double)c.y * o.y;   // conj(c) * o
+        ni += (double)c.x * o.y - (double)c.y * o.x;
+        dn += (double)c.x * c.x + (double)c.y * c.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nr += __shfl_down(nr, off, 64);
+        ni += __shfl_down(ni, off, 64);
+        dn += __shfl_down(dn, off, 64);
+    }
+    __shared__ double part[3][4];
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = nr;
+        part[1][threadIdx.x >> 6] = ni;
+        part[2][threadIdx.x >> 6] = dn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = part[0][0] + part[0][1] + part[0][2] + part[0][3], b = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        const double d = part[2][0] + part[2][1] + part[2][2] + part[2][3] + 1e-6;
+        coef[k].x = (float)(a / d);
+        coef[k].y = (float)(b / d);
+    }
+}
+
+// spectra times the per-frequency coefficient (second half of cuda_spectrum_update; cuda_filter1d, utilities.cu:765-773), or times
+// its conjugate (the transpose)
+__global__ void k_apply_coef(int nf, int nrec, hipfftComplex *__restrict__ spec, const hipfftComplex *__restrict__ coef, int conj) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (k >= nf || r >= nrec) return;
+    const float cr = coef[k].x, ci = conj ? -coef[k].y : coef[k].y;
+    hipfftComplex &v = spec[(size_t)r * nf + k];
+    const float x = v.x * cr - v.y * ci, y = v.x * ci + v.y * cr;
+    v.x = x;
+    v.y = y;
+}
+
 void fft_ok(hipfftResult r, const char *what) {
     if (r != HIPFFT_SUCCESS) throw std::runtime_error(std::string("hipFFT failure in ") + what + " (code " + std::to_string((int)r) + ")");
 }
@@ -150,6 +196,9 @@ Conditioner::~Conditioner() {
     (void)hipFree(pad_);
     (void)hipFree(spec_);
     (void)hipFree(norm_);
+    if (pad2_) (void)hipFree(pad2_);
+    if (spec2_) (void)hipFree(spec2_);
+    if (coef_) (void)hipFree(coef_);
 }
 
 long long Conditioner::device_bytes() const {
@@ -168,19 +217,8 @@ void Conditioner::bandpass(hipStream_t st, float *data, int nrec, float dt, cons
     if (nrec <= 0) return;
     if (nrec > cap_) throw std::invalid_argument("conditioning: more traces than the session was sized for");
     const int npad = 2 * nt_, nf = nt_ + 1;
-    auto it = plans_.find(nrec);
-    if (it == plans_.end()) {
-        Plans p{};
-        hipfftHandle f, b;
-        fft_ok(hipfftPlan1d(&f, npad, HIPFFT_R2C, nrec), "hipfftPlan1d(R2C)");
-        fft_ok(hipfftPlan1d(&b, npad, HIPFFT_C2R, nrec), "hipfftPlan1d(C2R)");
-        p.fwd = (void *)f;
-        p.inv = (void *)b;
-        it = plans_.emplace(nrec, p).first;
-    }
-    hipfftHandle f = (hipfftHandle)it->second.fwd, b = (hipfftHandle)it->second.inv;
-    fft_ok(hipfftSetStream(f, st), "hipfftSetStream");
-    fft_ok(hipfftSetStream(b, st), "hipfftSetStream");
+    Plans &pl = plans_for(nrec, st);
+    hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;
     hipLaunchKernelGGL(k_embed, dim3((npad + 255) / 256, nrec), dim3(256), 0, st, nt_, nrec, data, pad_);
     fft_ok(hipfftExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
     const float df = (float)(1.0 / (double)dt / (double)npad);
@@ -188,6 +226,70 @@ void Conditioner::bandpass(hipStream_t st, float *data, int nrec, float dt, cons
                        (hipfftComplex *)spec_);
     fft_ok(hipfftExecC2R(b, (hipfftComplex *)spec_, pad_), "hipfftExecC2R");
     hipLaunchKernelGGL(k_crop, dim3((nt_ + 255) / 256, nrec), dim3(256), 0, st, nt_, nrec, data, pad_, 1.0f / (float)npad);
+}
+
+Conditioner::Plans &Conditioner::plans_for(int nrec, hipStream_t st) {
+    auto it = plans_.find(nrec);
+    if (it == plans_.end()) {
+        Plans p{};
+        hipfftHandle f, b;
+        fft_ok(hipfftPlan1d(&f, 2 * nt_, HIPFFT_R2C, nrec), "hipfftPlan1d(R2C)");
+        fft_ok(hipfftPlan1d(&b, 2 * nt_, HIPFFT_C2R, nrec), "hipfftPlan1d(C2R)");
+        p.fwd = (void *)f;
+        p.inv = (void *)b;
+        it = plans_.emplace(nrec, p).first;
+    }
+    fft_ok(hipfftSetStream((hipfftHandle)it->second.fwd, st), "hipfftSetStream");
+    fft_ok(hipfftSetStream((hipfftHandle)it->second.inv, st), "hipfftSetStream");
+    return it->second;
+}
+
+void Conditioner::ensure_source_buffers() {
+    if (pad2_) return;
+    const size_t npad = 2 * (size_t)nt_, nf = (size_t)nt_ + 1;
+    if (hipMalloc((void **)&pad2_, npad * cap_ * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&spec2_, nf * cap_ * sizeof(hipfftComplex)) != hipSuccess ||
+        hipMalloc((void **)&coef_, nf * sizeof(hipfftComplex)) != hipSuccess)
+        throw std::runtime_error("conditioning: out of device memory (source update)");
+    if (hipMemset(coef_, 0, nf * sizeof(hipfftComplex)) != hipSuccess) throw std::runtime_error("conditioning: hipMemset failed");
+}
+
+// source_update, utilities.cu:1170-1281
+void Conditioner::source_update(hipStream_t st, const float *obs, float *syn, int nrec, float dt) {
+    if (nrec <= 0) return;
+    if (nrec > cap_) throw std::invalid_argument("conditioning: more traces than the session was sized for");
+    ensure_source_buffers();
+    const int npad = 2 * nt_, nf = nt_ + 1;
+    Plans &pl = plans_for(nrec, st);
+    hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;
+    const dim3 gpad((npad + 255) / 256, nrec), blk(256);
+    hipLaunchKernelGGL(k_embed, gpad, blk, 0, st, nt_, nrec, obs, pad_);
+    hipLaunchKernelGGL(k_embed, gpad, blk, 0, st, nt_, nrec, (const float *)syn, pad2_);
+    // cuda_window over the PADDED length, ratio 0.01 (utilities.cu:1199-1202)
+    hipLaunchKernelGGL(k_window, gpad, blk, 0, st, npad, nrec, dt, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1.0f, 0.01f, pad_);
+    hipLaunchKernelGGL(k_window, gpad, blk, 0, st, npad, nrec, dt, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1.0f, 0.01f, pad2_);
+    fft_ok(hipfftExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
+    fft_ok(hipfftExecR2C(f, pad2_, (hipfftComplex *)spec2_), "hipfftExecR2C");
+    hipLaunchKernelGGL(k_matching_coef, dim3(nf), blk, 0, st, nf, nrec, (const hipfftComplex *)spec_, (const hipfftComplex *)spec2_, (hipfftComplex *)coef_);
+    hipLaunchKernelGGL(k_apply_coef, dim3((nf + 255) / 256, nrec), blk, 0, st, nf, nrec, (hipfftComplex *)spec2_, (const hipfftComplex *)coef_, 0);
+    fft_ok(hipfftExecC2R(b, (hipfftComplex *)spec2_, pad2_), "hipfftExecC2R");
+    hipLaunchKernelGGL(k_crop, dim3((nt_ + 255) / 256, nrec), blk, 0, st, nt_, nrec, syn, pad2_, 1.0f / (float)npad);
+}
+
+void Conditioner::source_update_adj(hipStream_t st, float *res, int nrec, float dt) {
+    if (nrec <= 0) return;
+    if (nrec > cap_) throw std::invalid_argument("conditioning: more traces than the session was sized for");
+    ensure_source_buffers();
+    const int npad = 2 * nt_, nf = nt_ + 1;
+    Plans &pl = plans_for(nrec, st);
+    hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;
+    const dim3 gpad((npad + 255) / 256, nrec), blk(256);
+    hipLaunchKernelGGL(k_embed, gpad, blk, 0, st, nt_, nrec, (const float *)res, pad_);
+    fft_ok(hipfftExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
+    hipLaunchKernelGGL(k_apply_coef, dim3((nf + 255) / 256, nrec), blk, 0, st, nf, nrec, (hipfftComplex *)spec_, (const hipfftComplex *)coef_, 1);
+    fft_ok(hipfftExecC2R(b, (hipfftComplex *)spec_, pad_), "hipfftExecC2R");
+    hipLaunchKernelGGL(k_window, gpad, blk, 0, st, npad, nrec, dt, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1.0f, 0.01f, pad_);
+    hipLaunchKernelGGL(k_crop, dim3((nt_ + 255) / 256, nrec), blk, 0, st, nt_, nrec, res, pad_, 1.0f / (float)npad);
 }
 
 void Conditioner::l2_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, double *acc) {

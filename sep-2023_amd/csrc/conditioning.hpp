@@ -26,15 +26,26 @@ class Conditioner {
     // *acc += -2 sum_r <obs,syn>_r / (|obs|_r |syn|_r) w_r ; res = the adjoint source.  weights may be null (all ones).
     void cross_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, const float *weights, float src_weight,
                         double *acc);
+    // source_update (utilities.cu:1170-1281, cuda_spectrum_update :905-977): the source-signature update as a matching filter.
+    // Both gathers zero-padded to 2 nt and end-tapered over the padded length (ratio 0.01); per frequency one coefficient
+    // coef(f) = sum_r conj(C_r) O_r / (sum_r |C_r|^2 + 1e-6), kept for the adjoint step; the synthetic spectra are multiplied by
+    // it, transformed back, cropped.  `syn` is updated in place, `obs` is only read.
+    void source_update(hipStream_t st, const float *obs, float *syn, int nrec, float dt);
+    // transpose of the map syn -> updated syn at the coefficients of the last source_update: pad, FFT, conj(coef), inverse FFT,
+    // end taper of the padded length, crop.  (Conscious fix of source_update_adj, utilities.cu:1283-1325: oracle/oracle.py.)
+    void source_update_adj(hipStream_t st, float *res, int nrec, float dt);
     long long device_bytes() const;
 
   private:
     struct Plans {
         void *fwd, *inv;  // hipfftHandle
     };
+    Plans &plans_for(int nrec, hipStream_t st);
+    void ensure_source_buffers();
     int nt_, cap_;
-    float *pad_ = nullptr, *norm_ = nullptr;
+    float *pad_ = nullptr, *norm_ = nullptr, *pad2_ = nullptr;
     void *spec_ = nullptr;  // hipfftComplex [cap][nt + 1]
+    void *spec2_ = nullptr, *coef_ = nullptr;  // second padded gather / spectrum and the nt + 1 matching-filter coefficients (source update)
     std::map<int, Plans> plans_;  // by number of traces
 };
 

@@ -66,11 +66,13 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
                  const std::string &survey_text, const Params &par, const Survey &survey)
     : para_fname_(para_fname), gpu_id_(gpu_id), para_text_(para_text), survey_text_(survey_text), par_(par),
       survey_(survey) {
-    // The data-conditioning keys are dormant in the reference (every call site is commented out, libCUFD.cu:353-457, or acts
-    // on the pressure residual that is never injected, :430-433): computing something else than asked would be worse
-    // than refusing.
-    if (par.if_src_update) throw std::invalid_argument("parameter file: if_src_update is not supported");
-    cond_on_ = par.if_win || par.has_filter || par.if_cross_misfit;
+    // The data-conditioning keys are dormant in the reference (every call site is commented out, libCUFD.cu:353-457; the one live
+    // line, source_update_adj at :430-433, acts on the pressure residual that is never injected).  Here a key switches its
+    // stage on for the axial-strain gathers (conditioning.hip).  One combination has no defined meaning there either: the
+    // commented lines take the trace norms of the cross-correlation misfit BEFORE the source update and use them after it.
+    if (par.if_src_update && par.if_cross_misfit)
+        throw std::invalid_argument("parameter file: if_src_update together with if_cross_misfit is not supported");
+    cond_on_ = par.if_win || par.has_filter || par.if_cross_misfit || par.if_src_update;
     HIP_OK(hipSetDevice(gpu_id_));
     HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
@@ -600,10 +602,12 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const size_t tot = (size_t)rec_off_.back() + 1, off = (size_t)rec_off_[c.id];
         launch_transpose(st, syn_of(c, 3), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
         condition_gather(st, xpose_, c.id, c.nrec);
+        if (par_.if_src_update) cond_->source_update(st, c.d_obs, xpose_, c.nrec, par_.dt);   // libCUFD.cu:383-390
         if (par_.if_cross_misfit)
             cond_->cross_residual(st, c.d_obs, xpose_, xpose2_, c.nrec, win_ + 2 * tot + off, c.sh->src_weight, scal_);
         else
             cond_->l2_residual(st, c.d_obs, xpose_, xpose2_, c.nrec, scal_);
+        if (par_.if_src_update) cond_->source_update_adj(st, xpose2_, c.nrec, par_.dt);       // libCUFD.cu:430-433
         if (par_.has_filter) cond_->bandpass(st, xpose2_, c.nrec, par_.dt, par_.filter);  // adjoint of the (zero-phase) filter
         if (par_.if_win)
             cond_->window(st, xpose2_, c.nrec, par_.dt, win_ + off, win_ + tot + off, win_ + 2 * tot + off, c.sh->src_weight, 0.005f);
