@@ -63,7 +63,10 @@ int sepfwi_device_count(void);
  *                Shot_{pr,vx,vz,ett}{id}.bin, float32 [nrec][nSteps] (libCUFD.cu:216-223,755-769).
  *                One optional key beyond the reference's schema: "das_fiber": "horizontal" (default: ett = exx,
  *                recording_exx / res_injection_exx) or "vertical" (ett = ezz, recording_ezz / res_injection_ezz,
- *                Src/utilities.cu:620-641, which the reference reaches only through a source edit).
+ *                Src/utilities.cu:620-641, which the reference reaches only through a source edit).  Further optional keys
+ *                (INTEGRATION.md): "obs_pack_fname" -- one packed file of the survey's observed axial-strain gathers instead
+ *                of four files per shot; "if_win", "filter", "if_cross_misfit", "if_src_update" -- the data-conditioning
+ *                chain of Src/utilities.cu:733-1325, dormant in the reference's driver, live here for the axial-strain gathers.
  *
  * Unlike the reference, device state (fields, PML profiles, boundary buffers, observed data) is kept
  * in a per-(para_fname, gpu_id) session between calls; sepfwi_release_all() frees it.

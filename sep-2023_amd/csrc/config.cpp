@@ -34,6 +34,7 @@ Params parse_params(const std::string &text) {
     p.survey_fname = j.at("survey_fname").as_string("survey_fname");
     p.data_dir_name = j.at("data_dir_name").as_string("data_dir_name");
     if (j.has("scratch_dir_name")) p.scratch_dir_name = j.at("scratch_dir_name").as_string("scratch_dir_name");
+    if (j.has("obs_pack_fname")) p.obs_pack_fname = j.at("obs_pack_fname").as_string("obs_pack_fname");
     if (j.has("if_win")) p.if_win = j.at("if_win").as_bool("if_win");
     if (j.has("if_src_update")) p.if_src_update = j.at("if_src_update").as_bool("if_src_update");
     if (j.has("if_cross_misfit")) p.if_cross_misfit = j.at("if_cross_misfit").as_bool("if_cross_misfit");

@@ -12,6 +12,9 @@ struct Params {
     float dz = 0, dx = 0, dt = 0, f0 = 0;
     int nSteps = 0, nPml = 0, nPad = 0;
     std::string survey_fname, data_dir_name, scratch_dir_name;
+    // optional key "obs_pack_fname" (SURVEY.md 8f-2): ONE packed file of the survey's observed axial-strain gathers (layout:
+    // sepfwi/utils.py pack_observed) instead of the reference's four files per shot (libCUFD.cu:216-223)
+    std::string obs_pack_fname;
     // data-conditioning keys (dormant in the reference's driver, libCUFD.cu:353-457; live here, csrc/conditioning.hip)
     bool if_win = false, if_src_update = false, if_cross_misfit = false, has_filter = false;
     float filter[4] = {0, 0, 0, 0};  // band-pass corner frequencies [Hz]   (Parameter.cpp:147-159)

@@ -347,6 +347,40 @@ void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) 
     obs_[shot_id] = e;
 }
 
+// Byte offset of a shot's gather in the packed observed-data file (sepfwi/utils.py pack_observed), or -1 when the pack does not
+// hold the shot.  The index is re-read when the file changes.
+long long Session::pack_offset(int shot_id, int nrec) {
+    struct stat sb;
+    if (stat(par_.obs_pack_fname.c_str(), &sb) != 0) throw IoError("cannot read packed observed data '" + par_.obs_pack_fname + "'");
+    const long long stamp = (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec;
+    if (stamp != pack_mtime_ns_ || (long long)sb.st_size != pack_size_) {
+        pack_index_.clear();
+        FILE *fp = fopen(par_.obs_pack_fname.c_str(), "rb");
+        if (!fp) throw IoError("cannot read packed observed data '" + par_.obs_pack_fname + "'");
+        char magic[8];
+        int32_t head[2] = {0, 0};
+        bool ok = fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, "SEPFWIP1", 8) == 0 && fread(head, 4, 2, fp) == 2 && head[0] >= 0;
+        if (ok && head[1] != par_.nSteps) {
+            fclose(fp);
+            throw IoError("packed observed data '" + par_.obs_pack_fname + "' was written for another nSteps");
+        }
+        for (int k = 0; ok && k < head[0]; k++) {
+            int32_t e[2];
+            int64_t off;
+            ok = fread(e, 4, 2, fp) == 2 && fread(&off, 8, 1, fp) == 1;
+            if (ok) pack_index_[e[0]] = std::make_pair((long long)off, (int)e[1]);
+        }
+        fclose(fp);
+        if (!ok) throw IoError("'" + par_.obs_pack_fname + "' is not a packed observed-data file");
+        pack_mtime_ns_ = stamp;
+        pack_size_ = (long long)sb.st_size;
+    }
+    auto it = pack_index_.find(shot_id);
+    if (it == pack_index_.end()) return -1;
+    if (it->second.second != nrec) throw IoError("packed observed data: shot " + std::to_string(shot_id) + " has another channel count than the survey");
+    return it->second.first;
+}
+
 const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
     if (nrec <= 0) return nullptr;  // nothing to compare against
     {
@@ -354,19 +388,30 @@ const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
         if (im != obs_.end() && im->second.from_memory && im->second.bytes == (size_t)nrec * (size_t)par_.nSteps * sizeof(float))
             return im->second.d_ett;  // handed over through sepfwi_set_observed
     }
-    const std::string fn = shot_file(par_, 3, shot_id);
+    // where the gather lives: the survey's packed file when the parameter file names one and it holds this shot, else the
+    // shot's own Shot_ett{id}.bin (libCUFD.cu:216-223)
+    std::string fn = shot_file(par_, 3, shot_id);
+    long long file_off = 0;
+    const size_t want = (size_t)nrec * (size_t)par_.nSteps * sizeof(float);
+    if (!par_.obs_pack_fname.empty()) {
+        long long off = pack_offset(shot_id, nrec);
+        if (off >= 0) {
+            fn = par_.obs_pack_fname;
+            file_off = off;
+        }
+    }
     struct stat sb;
     if (stat(fn.c_str(), &sb) != 0) throw IoError("cannot read observed data '" + fn + "'");  // utilities.cu:12-16
-    const size_t want = (size_t)nrec * (size_t)par_.nSteps * sizeof(float);
-    if ((size_t)sb.st_size < want) throw IoError("observed data '" + fn + "' is shorter than nrec*nSteps floats");
+    if ((long long)sb.st_size < file_off + (long long)want) throw IoError("observed data '" + fn + "' is shorter than nrec*nSteps floats");
     auto it = obs_.find(shot_id);
     if (it != obs_.end() && it->second.mtime_ns == (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec &&
-        it->second.size == (long long)sb.st_size && it->second.bytes == want)
+        it->second.size == (long long)sb.st_size && it->second.bytes == want && !it->second.from_memory)
         return it->second.d_ett;
     FILE *fp = fopen(fn.c_str(), "rb");
     if (!fp) throw IoError("cannot read observed data '" + fn + "'");
     HIP_OK(hipStreamSynchronize(st));  // h_io_ / xpose_ may still be in use
-    size_t got = fread(h_io_, 1, want, fp);
+    size_t got = 0;
+    if (fseeko(fp, (off_t)file_off, SEEK_SET) == 0) got = fread(h_io_, 1, want, fp);
     fclose(fp);
     if (got != want) throw IoError("short read on '" + fn + "'");
     ObsEntry e;

@@ -45,6 +45,7 @@ class Session {
   private:
     template <class T> T *dalloc(size_t n);
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
+    long long pack_offset(int shot_id, int nrec);
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void order_after_null_stream(hipStream_t st);
@@ -114,6 +115,8 @@ class Session {
     PmlCoef pc_{};
     ImgAcc acc_{};
     std::map<int, ObsEntry> obs_;
+    std::map<int, std::pair<long long, int>> pack_index_;  // packed observed-data file: shot id -> (byte offset, nrec)
+    long long pack_mtime_ns_ = -1, pack_size_ = -1;
 
     double fwd_ms_ = 0, bwd_ms_ = 0, total_ms_ = 0;
     long long fwd_steps_ = 0, bwd_steps_ = 0, launches_ = 0;

@@ -35,7 +35,7 @@ def padding(cp, cs, den, nz_orig, nx_orig, nz, nx, nPml, nPad):
 
 def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir_name,
             if_win=False, filter_para=None, if_src_update=False, scratch_dir_name="", if_cross_misfit=False,
-            das_fiber="horizontal"):
+            das_fiber="horizontal", obs_pack_fname=None):
     """Write the one-line parameter JSON (schema of fwi_utils.py:46-83; nz, nx are the PADDED sizes).
     das_fiber (extension): "horizontal" = axial strain exx = vx(x) - vx(x-1), the reference's live
     choice; "vertical" = ezz = vz(z) - vz(z-1) (recording_ezz / res_injection_ezz, Src/utilities.cu:620-641, which the
@@ -61,6 +61,8 @@ def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname
     if scratch_dir_name != "":
         para["scratch_dir_name"] = scratch_dir_name
         os.makedirs(scratch_dir_name, exist_ok=True)
+    if obs_pack_fname:      # extension: one packed file of axial-strain gathers instead of four files per shot
+        para["obs_pack_fname"] = obs_pack_fname
     with open(para_fname, "w") as fp:
         json.dump(para, fp)
 
@@ -112,6 +114,46 @@ def sourceGene(f, nStep, delta_t):
 def read_shot_gather(data_dir, comp, shot_id, nSteps):
     """Shot_{pr|vx|vz|ett}{id}.bin -> (nrec, nSteps) float32 (libCUFD.cu:755-769)."""
     return np.fromfile(os.path.join(data_dir, "Shot_%s%d.bin" % (comp, shot_id)), dtype=np.float32).reshape(-1, nSteps)
+
+
+PACK_MAGIC = b"SEPFWIP1"
+
+
+def pack_observed(data_dir, shot_ids, nSteps, pack_fname):
+    """One file for a whole survey's observed axial-strain gathers instead of the reference's four files per
+    shot, of which only Shot_ett{id}.bin enters misfit and adjoint source (Src/libCUFD.cu:216-223,427,607).  Layout, little
+    endian:  8 bytes magic "SEPFWIP1" | int32 nEntries | int32 nSteps | nEntries x (int32 shot_id, int32 nrec, int64 byte offset)
+    | the gathers, float32 [nrec][nSteps] each, exactly the bytes of the Shot_ett files.  Named by the parameter key
+    "obs_pack_fname" (paraGen(..., obs_pack_fname=)); shots missing from the pack are still read from their own files."""
+    ids = [int(i) for i in shot_ids]
+    gathers = [read_shot_gather(data_dir, "ett", i, nSteps) for i in ids]
+    head = 8 + 8 + 16 * len(ids)
+    off = head
+    with open(pack_fname, "wb") as fp:
+        fp.write(PACK_MAGIC)
+        fp.write(np.array([len(ids), nSteps], dtype="<i4").tobytes())
+        for i, g in zip(ids, gathers):
+            fp.write(np.array([i, g.shape[0]], dtype="<i4").tobytes())
+            fp.write(np.array([off], dtype="<i8").tobytes())
+            off += g.size * 4
+        for g in gathers:
+            fp.write(np.ascontiguousarray(g, dtype="<f4").tobytes())
+    return pack_fname
+
+
+def read_packed_gather(pack_fname, shot_id):
+    """-> (nrec, nSteps) float32 of one shot of a pack_observed file."""
+    with open(pack_fname, "rb") as fp:
+        if fp.read(8) != PACK_MAGIC:
+            raise ValueError("%s is not a packed observed-data file" % pack_fname)
+        n, nSteps = np.frombuffer(fp.read(8), dtype="<i4")
+        for _ in range(int(n)):
+            sid, nrec = np.frombuffer(fp.read(8), dtype="<i4")
+            off = int(np.frombuffer(fp.read(8), dtype="<i8")[0])
+            if int(sid) == int(shot_id):
+                fp.seek(off)
+                return np.frombuffer(fp.read(int(nrec) * int(nSteps) * 4), dtype="<f4").reshape(int(nrec), int(nSteps)).copy()
+    raise KeyError("shot %d is not in %s" % (shot_id, pack_fname))
 
 
 # Mineral / fluid constants of the reference's rock-physics maps (fwi_utils.py:156-167,311-322; FWI_ops.py:452-462,573-584):

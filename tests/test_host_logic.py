@@ -307,3 +307,23 @@ def test_wrong_shapes_are_refused_before_the_library_sees_them(tmp_path):
             fwi_ops._cufd(1, 0, a["Lambda"], a["Mu"], a["Den"], a["Stf"], a["ids"], pb["para_fname"])
     with pytest.raises(TypeError):
         fwi_ops._cufd(1, 0, lam.double(), mu, den, pb["Stf"], pb["Shot_ids"], pb["para_fname"])
+
+
+def test_packed_observed_file_round_trip(tmp_path):
+    """utils.pack_observed / read_packed_gather: the pack holds exactly the bytes of the Shot_ett files."""
+    from sepfwi import utils as ft
+    rng = np.random.default_rng(1)
+    d = str(tmp_path)
+    nS = 37
+    g = {sid: rng.standard_normal((5 + sid, nS)).astype(np.float32) for sid in (0, 3, 4)}
+    for sid, a in g.items():
+        a.tofile(os.path.join(d, "Shot_ett%d.bin" % sid))
+    pack = ft.pack_observed(d, [4, 0, 3], nS, os.path.join(d, "all.pack"))
+    for sid, a in g.items():
+        assert np.array_equal(ft.read_packed_gather(pack, sid), a)
+    assert os.path.getsize(pack) == 16 + 3 * 16 + sum(a.size * 4 for a in g.values())
+    with pytest.raises(KeyError):
+        ft.read_packed_gather(pack, 1)
+    para = os.path.join(d, "p.json")
+    ft.paraGen(64, 64, 10.0, 10.0, nS, 1e-3, 10.0, 8, 0, para, os.path.join(d, "s.json"), os.path.join(d, "Data"), obs_pack_fname=pack)
+    assert json.load(open(para))["obs_pack_fname"] == pack
