@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: gpu_bench_profile.sh <tag>   -- the record run of a round: full bench line, rocprofv3 kernel-trace summary of the same
 # command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic.  Copies the summaries to gpurun_out/<tag>_*.
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 ( time timeout -k 10 600 python bench.py --steps 4 --warmup 1 ) > gpurun_out/${TAG}_bench_full.log 2>&1 || exit 1
@@ -22,3 +22,6 @@ rm -f gpurun_out/prof_$TAG/trace/*/*kernel_trace.csv   # 22 MB raw trace: the st
 # configs[1] shape, forward only, un-profiled
 ( timeout -k 10 300 python bench.py --mode fwd --nz 500 --nsteps 2000 --steps 3 --warmup 1 --no-cpu-baseline ) > gpurun_out/${TAG}_fwd2000x500_bench.log 2>&1
 tail -1 gpurun_out/${TAG}_fwd2000x500_bench.log | cut -c1-400
+# configs[3]'s per-GPU load in one call: 32 shots per step (one step: 10.8 s)
+( timeout -k 10 400 python bench.py --shots-per-step 32 --steps 1 --warmup 0 --no-cpu-baseline ) > gpurun_out/${TAG}_bench_32shots.log 2>&1
+tail -1 gpurun_out/${TAG}_bench_32shots.log | cut -c1-400
