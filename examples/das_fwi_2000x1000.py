@@ -72,7 +72,9 @@ def main():
     ap.add_argument("--nz", type=int, default=1000)
     ap.add_argument("--nx", type=int, default=2000)
     ap.add_argument("--nsteps", type=int, default=4000)
-    ap.add_argument("--no-bounds", action="store_true")
+    ap.add_argument("--no-bounds", action="store_true",
+                    help="run unconstrained like the reference's experiments (on this synthetic start the first steps then leave the\n"
+                         "Courant limit); with bounds SciPy spends 10-20 s per minimize() call turning 6 M bounds into Python lists")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
