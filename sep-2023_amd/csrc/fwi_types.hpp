@@ -35,7 +35,6 @@ struct Grid {
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
     int amu_fly;  // 1: the 4-point harmonic mean of mu recomputed from mu in the stress-type kernels
     int nb, shot_fastest;  // batched launches: shots per grid and the order of (tile, shot) in the block index
-    int dbg;               // timing experiments only (option "dbg"): ablation bits of k_bwd_fused, results are wrong when set
 };
 
 // Five wavefields (or their adjoint twins), each nzc*pitch floats.

@@ -595,8 +595,6 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
     }
 }
 
-#include "bwd_fused.inc.hpp"
-
 // ---------------------------------------------------------------------------------------------
 // Batched forms: the block index encodes (tile, shot of the batch) -- my_cell(); per-shot pointers in a ShotDev table in device memory.
 // One launch advances EVERY shot of the batch by a half step.  Small grids stop being launch-bound (the reference issues
@@ -916,7 +914,7 @@ struct OptField {
 };
 const OptField kOptFields[] = {
     {"bz", &KernelOptions::bz, 1, 16},           {"xcd_remap", &KernelOptions::xcd_remap, 0, 1},
-    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 3}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
+    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 2}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
     {"pair_fwd", &KernelOptions::pair_fwd, 0, 1}, {"fwd_lanes", &KernelOptions::fwd_lanes, 1, 4},
     {"early", &KernelOptions::early, 0, 3},       {"rho_fly", &KernelOptions::rho_fly, 0, 3},
     {"amu_fly", &KernelOptions::amu_fly, 0, 3},   {"rk_lazy", &KernelOptions::rk_lazy, 0, 1},
@@ -924,8 +922,6 @@ const OptField kOptFields[] = {
     {"batch_b", &KernelOptions::batch_b, 0, 64},  {"batch_mb", &KernelOptions::batch_mb, 1, 1 << 20},
     {"batch_order", &KernelOptions::batch_order, 0, 1},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
-    {"fuse_cfg", &KernelOptions::fuse_cfg, 0, 5},
-    {"dbg", &KernelOptions::dbg, 0, 1 << 20},
 };
 }  // namespace
 
@@ -1033,35 +1029,6 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
     else
         hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
-}
-
-// the whole backward step in one launch (bwd_fused.inc.hpp); set_in / set_out are the two ping-pong sets of the step, each
-// [5 fields | 8 memory variables | 5 adjoint fields] with stride n
-void launch_bwd_fused(hipStream_t st, const Grid &g0, const KernelOptions &o, const float *set_in, float *set_out, size_t n, Media md,
-                      PmlCoef pc, const float *frame_t, int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it,
-                      ImgAcc acc, LineRec lr, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const Grid &g = g0;
-    static const int cfgW[6] = {4, 4, 4, 2, 4, 2}, cfgR[6] = {5, 3, 4, 6, 7, 10};
-    const int W = cfgW[o.fuse_cfg], R1 = cfgR[o.fuse_cfg];
-    const int gx = (g.nx + FUSED_NXO - 1) / FUSED_NXO, gy = (g.nzc + (W * R1 - 4) - 1) / (W * R1 - 4);
-    if (o.dbg & 32) set_out = const_cast<float *>(set_in);  // timing experiment: in place (wrong results), half the footprint
-    const FusedArgs a{set_in, set_out, md.lam, acc.lam, pc.a_z, frame_t, stf_grad_it, lr.res, (unsigned)(n * sizeof(float)),
-                      g.nzc, g.nx, g.pitch, g.nPml, g.nzBnd, g.nxBnd, g.frame_len, gx, gx * gy, g.dt, g.rdz, g.rdx,
-                      (z_src << 16) | x_src, src_amp, src_rxz, (lr.z << 16) | lr.x0, lr.n, o.dbg};
-    void (*k)(FusedArgs) = nullptr;
-    switch (o.fuse_cfg) {
-        case 0: k = k_bwd_fused<4, 5>; break;    // tile 64 x 16
-        case 1: k = k_bwd_fused<4, 3>; break;    // 64 x 8
-        case 2: k = k_bwd_fused<4, 4>; break;    // 64 x 12
-        case 3: k = k_bwd_fused<2, 6>; break;    // 64 x 8, two waves
-        case 4: k = k_bwd_fused<4, 7>; break;    // 64 x 24
-        default: k = k_bwd_fused<2, 10>; break;  // 64 x 16, two waves
-    }
-    const dim3 grid(((gx * gy + 7) / 8) * 8), block(64 * W);
-    if (ev_start)
-        hipExtLaunchKernelGGL(k, grid, block, 0, st, ev_start, ev_stop, 0, a);
-    else
-        hipLaunchKernelGGL(k, grid, block, 0, st, a);
 }
 
 __global__ void k_add_inplace(float *__restrict__ a, const float *__restrict__ b, size_t n) {

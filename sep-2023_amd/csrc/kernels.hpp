@@ -11,8 +11,7 @@ namespace sepfwi {
 struct KernelOptions {
     int bz = 2;           // waves (rows) per block of the field kernels
     int xcd_remap = 1;    // 1: each XCD gets a contiguous band of tiles
-    int bwd_fuse = 2;     // backward step: 0 the reference's four kernels (+ k_inject), 2 cross-chain pairs k_bwd_a / k_bwd_b,
-                          // 3 the whole step in one launch (k_bwd_fused, ping-pong state; stream mode only)
+    int bwd_fuse = 2;     // backward step: 0 the reference's four kernels (+ k_inject), 2 cross-chain pairs k_bwd_a / k_bwd_b
     int line_fuse = 1;    // 1: line receivers are sampled / injected inside the field kernels
     int pair_fwd = 1;     // 1: forward passes of several shots run concurrently (one stream each, or one batched launch)
     int fwd_lanes = 3;    // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
@@ -26,8 +25,6 @@ struct KernelOptions {
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
-    int dbg = 0;          // timing experiments only: ablation bits of k_bwd_fused (results are wrong when set)
-    int fuse_cfg = 0;     // bwd_fuse = 3: tile of the one-launch backward step, waves x region rows per wave: 0 4x5, 1 4x3, 2 4x4, 3 2x6, 4 4x7, 5 2x10
 };
 KernelOptions kernel_options();                       // snapshot of the defaults
 int get_kernel_option(const char *name);              // -1: unknown
@@ -47,9 +44,6 @@ void launch_bwd_a(hipStream_t st, const Grid &g, const KernelOptions &o, Fields 
 void launch_bwd_b(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
                   int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-void launch_bwd_fused(hipStream_t st, const Grid &g, const KernelOptions &o, const float *set_in, float *set_out, size_t n, Media md,
-                      PmlCoef pc, const float *frame_t, int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it,
-                      ImgAcc acc, LineRec lr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // batched forms (one grid over tiles x shots of the batch; ShotDev table in device memory)
 void launch_stress_fwd_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                              PmlCoef pc, size_t n, size_t data_len, int it, float src_scale, bool save);

@@ -228,7 +228,6 @@ Session::~Session() {
     for (auto &kv : obs_) (void)hipFree(kv.second.d_ett);
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
-    if (alt_) (void)hipFree(alt_);
     if (stf_grad_) (void)hipFree(stf_grad_);
     if (h_io_) (void)hipHostFree(h_io_);
     for (auto &e : ev_) (void)hipEventDestroy(e);
@@ -518,12 +517,6 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         device_bytes_ += (long long)fb;
     }
     if (withAdj) HIP_OK(hipMemsetAsync(acc_buf_, 0, 5 * n * sizeof(float), st));  // Model.cu:68-71
-    if (withAdj && opt.bwd_fuse == 3 && !alt_) {  // second state set of the one-launch backward step
-        if (18 * n * sizeof(float) >= (size_t)1 << 31) throw std::invalid_argument("bwd_fuse = 3 addresses a state set with 32-bit byte offsets: grid too large");
-        HIP_OK(hipMalloc((void **)&alt_, 36 * n * sizeof(float)));
-        device_bytes_ += (long long)(36 * n * sizeof(float));
-        HIP_OK(hipMemsetAsync(alt_, 0, 36 * n * sizeof(float), st));
-    }
     if (if_res) HIP_OK(hipMemsetAsync(scal_, 0, 4 * sizeof(double), st));
 
     // ---- source traces on the host: row shot_ids[i] of stf, tapered (Src_Rec.cu:130-137) ----
@@ -758,19 +751,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             e1 = probe_ev_[2 * n_probe + 1];
             n_probe++;
         }
-        if (fuse_bwd == 3) {
-            // one launch per step; the state ping-pongs between the two halves of alt_ (even steps of the pass read the
-            // first).  A general receiver set is injected into the step's OUTPUT adjoint velocities.
-            const size_t nn = cells_;
-            const bool even = ((nSteps - 2 - it) & 1) == 0;
-            float *set_in = even ? alt_ : alt_ + 18 * nn, *set_out = even ? alt_ + 18 * nn : alt_;
-            launch_bwd_fused(L.s, g, opt, set_in, set_out, nn, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.acc, lr, e0, e1);
-            if (!inj_inl) {
-                const Fields a_out{set_out + 13 * nn, set_out + 14 * nn, set_out + 15 * nn, set_out + 16 * nn, set_out + 17 * nn};
-                launch_inject(L.s, g, a_out, c.nrec, c.rec, res_t, c.sens);
-            }
-            launches_ += inj_inl ? 1 : 2;
-        } else if (fuse_bwd == 2) {
+        if (fuse_bwd == 2) {
             launch_bwd_a(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
             launch_bwd_b(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
             if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
@@ -797,17 +778,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const BwdLane L{st, mem_, adj_, acc_};
         HIP_OK(hipEventRecord(ev_[2], st));
         backward_init(L);
-        if (fuse_bwd == 3) {  // both ping-pong sets: memories + adjoint fields zero, the first set starts from the lane's final forward fields
-            HIP_OK(hipMemsetAsync(alt_ + 5 * n, 0, 13 * n * sizeof(float), st));
-            HIP_OK(hipMemsetAsync(alt_ + 23 * n, 0, 13 * n * sizeof(float), st));
-            HIP_OK(hipMemcpyAsync(alt_, c.state, 5 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        }
         for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
-        if (fuse_bwd == 3) {  // final reconstructed and adjoint fields back where debug_field looks for them
-            const float *fin = alt_ + (((nSteps - 1) & 1) ? 18 * n : 0);
-            HIP_OK(hipMemcpyAsync(c.state, fin, 5 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
-            HIP_OK(hipMemcpyAsync(adj_.vz, fin + 13 * n, 5 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        }
         HIP_OK(hipEventRecord(ev_[3], st));
         bwd_steps_ += (long long)(nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));

@@ -98,7 +98,6 @@ class Session {
     size_t d_stf_len_ = 0;
     bool last_batched_ = false;
     float *state_ = nullptr, *media_ = nullptr, *acc_buf_ = nullptr, *in_stage_ = nullptr, *grad_stage_ = nullptr;
-    float *alt_ = nullptr;  // bwd_fuse = 3: the two [5 fields | 8 memories | 5 adjoint fields] sets the one-launch backward step ping-pongs between
     float *frame_ = nullptr, *syn_ = nullptr, *res_ = nullptr, *xpose_ = nullptr, *stf_grad_ = nullptr, *h_io_ = nullptr;
     double *scal_ = nullptr;
     unsigned int *cp2_bits_ = nullptr;
