@@ -113,8 +113,8 @@ class _FwiOps:
                                   ptr(Stf), int(calc_id), gpu_id, int(ids.size), C.c_void_p(ids.ctypes.data),
                                   str(para_fname).encode(), stream, 0)
         _native.check(rc)
-        if calc_id == 1 and gL.device != dev:
-            gL, gM, gD = gL.to(dev), gM.to(dev), gD.to(dev)
+        if calc_id == 1 and gL.device != dev:   # single-process ngpu > 1: every block's results return to the model's device
+            gL, gM, gD, misfit = gL.to(dev), gM.to(dev), gD.to(dev), misfit.to(dev)
         return misfit, gL, gM, gD, gS
 
     def _device_for(self, t: torch.Tensor, i: int, ngpu: int = 1) -> int:
