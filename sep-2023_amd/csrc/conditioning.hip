@@ -202,7 +202,9 @@ Conditioner::~Conditioner() {
 }
 
 long long Conditioner::device_bytes() const {
-    return (long long)(2 * (size_t)nt_ * cap_ * sizeof(float) + ((size_t)nt_ + 1) * cap_ * sizeof(hipfftComplex) + 3 * (size_t)cap_ * sizeof(float));
+    const size_t pad = 2 * (size_t)nt_ * cap_ * sizeof(float), spec = ((size_t)nt_ + 1) * cap_ * sizeof(hipfftComplex);
+    const size_t src = pad2_ ? pad + spec + ((size_t)nt_ + 1) * sizeof(hipfftComplex) : 0;  // source-update buffers, allocated on first use
+    return (long long)(pad + spec + 3 * (size_t)cap_ * sizeof(float) + src);
 }
 
 void Conditioner::window(hipStream_t st, float *data, int nrec, float dt, const float *win_start, const float *win_end,
