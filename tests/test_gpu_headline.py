@@ -6,8 +6,10 @@
 * The full 2000 x 1000 x 4000 configuration through a size-independent property: after the
   backward pass the reverse-time reconstruction has been run back to time step 0 and must have returned to the zero
   initial state to <= 1e-5 of the peak forward amplitude.
-* BASELINE.json configs[1] (2000 x 500, 2000 steps, forward only): full-size properties plus an oracle-checked cropped
-  twin of the same model, spacing, time step and source.
+* BASELINE.json configs[1] (2000 x 500, 2000 steps, forward only): against the CPU oracle at full size (round 3), full-size
+  properties, plus an oracle-checked cropped twin of the same model, spacing, time step and source.
+* BASELINE.json configs[2] (2000 x 1000, 4000 steps, forward + adjoint): one shot and all 32 shots against the CPU oracle at
+  full size (round 3), the 32-shot call against the sum of its groups.
 """
 import hashlib
 import os
@@ -134,6 +136,16 @@ def test_config1_shape_2000x500_forward_only(tmp_path, hip_ops, oracle):
     for c, a in d1.items():
         assert a.shape == (pb["nrec"], nS) and np.isfinite(a).all() and np.abs(a).max() > 0, c
         assert np.all(a[:, 0] == 0.0), c                                   # column 0 stays zero (Appendix A-7)
+    # round 3: the same run through the CPU oracle at the FULL size (scripts/make_golden_config1shape.py): 32 channels of every
+    # component and the norms over all 1980
+    import scripts.make_golden_config1shape as mc
+    G = np.load(os.path.join(ROOT, "tests", "golden", "oracle_config1shape.npz"))
+    assert mc.digest(pb) == str(G["digest"]), "bench.py's problem generator drifted: regenerate with scripts/make_golden_config1shape.py"
+    dev = {c: P.rel_l2(d1[c][G["channels"]], G[c]) for c in ("pr", "vx", "vz", "ett")}
+    print("configs[1] at full size, HIP vs oracle, rel-L2 per component:", dev)
+    assert max(dev.values()) <= 1e-4, dev
+    for c in dev:
+        assert abs(np.linalg.norm(d1[c].astype(np.float64)) - float(G[c + "_norm"])) <= 1e-4 * float(G[c + "_norm"]), c
     assert np.array_equal(d1["ett"][1:], d1["vx"][1:] - d1["vx"][:-1])       # consecutive channels: exx_r = vx_r - vx_(r-1), exactly
     assert np.abs(d1["vz"][:, nS // 2:]).max() > 0                           # the wavefield is alive in the second half
     hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, ids, pb["para_fname"])       # bit-identical repeat
@@ -307,3 +319,55 @@ def test_headline_full_size_matches_oracle(tmp_path, hip_ops):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "headline_vs_oracle.txt"), "w") as fp:
         fp.write("2000x1000x4000, one shot, HIP path vs CPU oracle (tests/golden/oracle_headline.npz)\nobserved gather rel-L2: %r\ngradient call: %r\n" % (dev, out))
+
+
+HEADLINE32_GOLDEN = os.path.join(ROOT, "tests", "golden", "oracle_headline32.npz")
+
+
+@pytest.mark.timeout(900)
+def test_headline_32_shots_match_oracle(tmp_path, hip_ops):
+    """BASELINE.json configs[2] LITERALLY: "2000 x 1000 model, 32 shots, forward + boundary-saving adjoint gradient on 1 MI355X,
+    grad checked vs reference" -- ONE 32-shot call of the HIP path against the CPU oracle's 32 shots (0.9e12 cell-updates on
+    the host, scripts/make_golden_headline32.py; per-shot float32 gradients summed in float64).  Observed data: modelled by
+    this library (the oracle's 1 GB of gathers are not committed; the single-shot test compares them channel by channel)."""
+    if not os.path.exists(HEADLINE32_GOLDEN):
+        pytest.skip("tests/golden/oracle_headline32.npz not generated (scripts/make_golden_headline32.py, about 3 hours of CPU)")
+    sys.path.insert(0, ROOT)
+    import bench
+    import scripts.make_golden_headline32 as mg
+    from sepfwi import utils as ft
+    G = np.load(HEADLINE32_GOLDEN)
+    nS, n_shots = mg.NSTEPS, mg.NSHOTS
+    assert int(G["n_shots"]) == n_shots
+    pb = bench.setup_problem(str(tmp_path), mg.NZ, mg.NX, nS, n_shots)
+    assert mg.digest(pb) == str(G["digest"]), "bench.py's problem generator drifted: regenerate with scripts/make_golden_headline32.py"
+    lt, mt, dt_ = [t.cuda() for t in pb["lame_true"]]
+    lam, mu, den = [t.cuda() for t in pb["lame_init"]]
+    data_dir = str(tmp_path / "Data")
+    for k in range(0, n_shots, 4):
+        grp = torch.arange(k, min(k + 4, n_shots), dtype=torch.int32)
+        hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, grp, pb["para_fname"])
+        for sid in grp.tolist():
+            hip_ops.set_observed(pb["para_fname"], sid, torch.from_numpy(ft.read_shot_gather(data_dir, "ett", sid, nS).copy()))
+            for c in ("pr", "vx", "vz", "ett"):
+                os.remove(os.path.join(data_dir, "Shot_%s%d.bin" % (c, sid)))
+    ids = torch.arange(n_shots, dtype=torch.int32)
+    m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    out = {"misfit": abs(float(m) - float(G["misfit"])) / float(G["misfit"])}
+    assert out["misfit"] <= 1e-4, (float(m), float(G["misfit"]))
+    d = int(G["decim"])
+    z0, z1, x0, x1 = [int(v) for v in G["win"]]
+    for key, g in (("gLambda", gL), ("gMu", gM), ("gDen", gD)):
+        g = g.cpu().numpy()
+        gmax = float(G[key + "_max"])
+        dec, win = g[::d, ::d], g[z0:z1, x0:x1]
+        out[key] = (P.rel_l2(dec, G[key + "_dec"]), P.rel_l2(win, G[key + "_win"]),
+                    abs(np.linalg.norm(g.astype(np.float64)) - float(G[key + "_norm"])) / float(G[key + "_norm"]))
+        assert max(out[key]) <= 1e-3, (key, out[key])
+        assert np.abs(dec - G[key + "_dec"]).max() <= 1e-3 * gmax and np.abs(win - G[key + "_win"]).max() <= 1e-3 * gmax, key
+    out["gStf"] = P.rel_l2(gS.numpy(), G["gStf"])
+    assert out["gStf"] <= 1e-3, out
+    print("32-shot call vs the oracle's 32 shots: misfit rel, (rel-L2 every 8th cell, window, rel norm) per gradient, gStf:", out)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "headline32_vs_oracle.txt"), "w") as fp:
+        fp.write("2000x1000x4000, 32 shots in one call, HIP path vs CPU oracle (tests/golden/oracle_headline32.npz): %r\n" % out)
