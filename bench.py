@@ -339,7 +339,11 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": kern,
                              "avg_us": round(per_step_us, 2),
-                             "whole_job_frac": round(value * (BYTES_PER_UPDATE_FWDADJ if args.mode == "fwdadj" else BYTES_FWD) / world / HBM_PEAK_GBPS, 4)},
+                             "whole_job_frac": round(value * (BYTES_PER_UPDATE_FWDADJ if args.mode == "fwdadj" else BYTES_FWD) / world / HBM_PEAK_GBPS, 4),
+                             # un-apportioned cross-checks from the session's own HIP-event timing of the time loops: 60 B per cell
+                             # and forward step, 124 B per cell and backward step
+                             "fwd_step_frac": round(pb["n_c"] * BYTES_FWD / (fwd_ms * 1e3 / nst * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if fwd_ms > 0 else None,
+                             "bwd_step_frac": round(pb["n_c"] * 124.0 / (bwd_ms * 1e3 / nst * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if bwd_ms > 0 else None},
                 "fwd_ms_per_shot": round(fwd_ms / (K * spr), 2), "bwd_ms_per_shot": round(bwd_ms / (K * spr), 2),
                 "fwd_us_per_time_step": round(fwd_ms * 1e3 / nst, 2), "bwd_us_per_time_step": round(bwd_ms * 1e3 / nst, 2),
             }
