@@ -135,7 +135,9 @@ int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
  * Kernel / scheduling options for A/B measurements and for the parity tests of every selectable structure.
  * Names and defaults (struct KernelOptions, csrc/kernels.hpp): bz 2, xcd_remap 1, bwd_fuse 2 (0: the reference's four
  * kernels per backward step), line_fuse 1, pair_fwd 1, fwd_lanes 3, early 0, rho_fly 1, amu_fly 1, rk_lazy 1, batch 2
- * (0 streams, 1 batched launches, 2 by grid size), batch_f 0, batch_b 0, batch_mb 200, batch_order 1, probe 0.
+ * (0 streams, 1 batched launches, 2 by grid size), batch_f 0, batch_b 0, batch_mb 200, batch_order 1, probe 0, img_every 1
+ * (k > 1: the imaging condition on every k-th backward step with weight k dt -- an opt-in quadrature of the same time integrals,
+ * gradients within 1e-4 of every-step imaging for the usual wavelets; NOT covered by the next sentence).
  * sepfwi_set_option edits the process-wide defaults under a lock; every sepfwi_cufd* call takes ONE snapshot of them when
  * it starts, so a call never sees a half-changed block and concurrent calls on other GPUs are unaffected.  Results are
  * identical (to the parity tolerances) for every setting.  Returns SEPFWI_EINVAL for unknown names or values;

@@ -22,6 +22,8 @@ struct Grid {
     int xmax;   // last interior column = nx  - 1 - nPml
     int nSteps;
     float dt;
+    float dt_img;    // time weight of the imaging condition in this launch: dt (every step, the reference), k dt on every k-th step and 0
+                     // (imaging skipped) on the others with option img_every = k
     float rdz, rdx;  // 1/dz, 1/dx
     float dz, dx;
     // boundary frame geometry (Boundary.cu:17-27): rows/cols [nPml-2, nPml-2+n?Bnd)

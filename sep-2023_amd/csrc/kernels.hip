@@ -196,16 +196,22 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             const float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
             const float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
             const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
-            const float za = adj.szz[i], xa = adj.sxx[i], sa = adj.sxz[i];
-            const float g_lam = acc.lam[i], g_mu = acc.mu[i], g_xz = acc.xz[i];
+            const bool img = g.dt_img != 0.0f;  // launch-uniform: option img_every images every k-th step only
+            float za = 0.f, xa = 0.f, sa = 0.f, g_lam = 0.f, g_mu = 0.f, g_xz = 0.f;
+            if (img) {
+                za = adj.szz[i]; xa = adj.sxx[i]; sa = adj.sxz[i];
+                g_lam = acc.lam[i]; g_mu = acc.mu[i]; g_xz = acc.xz[i];
+            }
             const float l2m = lam + 2.0f * mu;
             szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
             sxx -= (lam * dvz_dz + l2m * dvx_dx) * g.dt;
             sxz -= amu * (dvx_dz + dvz_dx) * g.dt;
-            // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
-            acc.lam[i] = g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt;
-            acc.mu[i] = g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt;
-            acc.xz[i] = g_xz + -sa * (dvx_dz + dvz_dx) * g.dt;
+            if (img) {
+                // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
+                acc.lam[i] = g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img;
+                acc.mu[i] = g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img;
+                acc.xz[i] = g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img;
+            }
         }
         if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
             const int L = g.frame_len;
@@ -286,14 +292,20 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             const float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
             const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
             const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
-            const float g_a = acc.a[i], g_b = acc.b[i], avz = adj.vz[i], avx = adj.vx[i];
+            const bool img = g.dt_img != 0.0f;  // launch-uniform
+            float g_a = 0.f, g_b = 0.f, avz = 0.f, avx = 0.f;
+            if (img) {
+                g_a = acc.a[i]; g_b = acc.b[i]; avz = adj.vz[i]; avx = adj.vx[i];
+            }
             float ba, bb;
             buoyancies(g, md, i, ba, bb);
             vz = f.vz[i] - (dszz_dz + dsxz_dx) * ba * g.dt;
             vx = f.vx[i] - (dsxz_dz + dsxx_dx) * bb * g.dt;
-            // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
-            acc.a[i] = g_a + -avz * (dszz_dz + dsxz_dx) * g.dt;
-            acc.b[i] = g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt;
+            if (img) {
+                // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
+                acc.a[i] = g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img;
+                acc.b[i] = g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img;
+            }
         }
         if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
             const int L = g.frame_len;
@@ -922,6 +934,7 @@ const OptField kOptFields[] = {
     {"batch_b", &KernelOptions::batch_b, 0, 64},  {"batch_mb", &KernelOptions::batch_mb, 1, 1 << 20},
     {"batch_order", &KernelOptions::batch_order, 0, 1},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
+    {"img_every", &KernelOptions::img_every, 1, 64},
 };
 }  // namespace
 

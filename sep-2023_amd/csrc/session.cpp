@@ -90,6 +90,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     g.xmax = par.nx - 1 - par.nPml;
     g.nSteps = par.nSteps;
     g.dt = par.dt;
+    g.dt_img = par.dt;
     g.dz = par.dz;
     g.dx = par.dx;
     g.rdz = 1.0f / par.dz;
@@ -751,14 +752,16 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             e1 = probe_ev_[2 * n_probe + 1];
             n_probe++;
         }
+        Grid gs = g;  // this step's imaging weight (option img_every)
+        if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
         if (fuse_bwd == 2) {
-            launch_bwd_a(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
-            launch_bwd_b(L.s, g, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
+            launch_bwd_a(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
+            launch_bwd_b(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
             if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
             launches_ += inj_inl ? 2 : 3;
         } else {  // the reference's launch structure
-            launch_velocity_rev(L.s, g, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
-            launch_stress_rev(L.s, g, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
+            launch_velocity_rev(L.s, gs, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
+            launch_stress_rev(L.s, gs, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
             launch_velocity_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
             launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
             launch_stress_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
@@ -898,8 +901,10 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                         e1 = probe_ev_[2 * n_probe + 1];
                         n_probe++;
                     }
-                    launch_bwd_a_batch(st, g, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
-                    launch_bwd_b_batch(st, g, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, src_scale, e0, e1);
+                    Grid gs = g;
+                    if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
+                    launch_bwd_a_batch(st, gs, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
+                    launch_bwd_b_batch(st, gs, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, src_scale, e0, e1);
                     launches_ += 2;
                     for (int k = 0; k < nbb; k++)
                         if (tab[is0 + kb + k].lr_n == 0) {
