@@ -209,3 +209,45 @@ def test_bench_spawns_its_own_ranks():
     if torch.cuda.device_count() >= 2:
         rc = _run_bench(["--gpus", "2"])
         assert rc["n_gpus"] == 2 and rc["value"] > 0
+
+
+def _rccl_one_rank_worker(port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "sep-2023_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as td
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from sepfwi import dist
+    n, shape = 37 * 53, (37, 53)
+    fused = torch.arange(3 * n + 1, dtype=torch.float32, device="cuda") * 0.5
+    want = fused.clone()
+    gL, gM, gD = (fused[k * n:(k + 1) * n].view(shape) for k in range(3))
+    m = fused[3 * n:3 * n + 1]
+    ncoll = [0]
+    real = td.all_reduce
+
+    def counting(*a, **k):
+        ncoll[0] += 1
+        return real(*a, **k)
+    td.all_reduce = counting
+    view = dist.fused_view(m, gL, gM, gD)
+    m2, a, b, c = dist.allreduce_gradients(m, gL, gM, gD)
+    torch.cuda.synchronize()
+    ok = (view is not None and view.data_ptr() == fused.data_ptr() and ncoll[0] == 1 and torch.equal(fused, want)
+          and a.data_ptr() == gL.data_ptr() and m2.data_ptr() == m.data_ptr() and td.get_backend() == "nccl")
+    q.put(bool(ok))
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_reduces_the_fused_buffer_in_place_single_rank():
+    """The one-GPU box cannot hold two RCCL ranks, but it can run RCCL: a one-rank `nccl` group sums the fused gradient buffer
+    [gL | gM | gD | misfit] exactly as the multi-rank path hands it over -- the session's own allocation, recognised by
+    dist.fused_view, ONE collective, no staging copy (same storage before and after), values unchanged by a sum over one rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    ok = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0 and ok
