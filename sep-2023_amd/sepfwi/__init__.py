@@ -7,6 +7,7 @@ Host side (Python, mirrors DAS_Waveform_Inversion/Ops/FWI of the reference):
     modules.FWI ...        parameterisation modules (FWI_ops.py:66-619): callers of the operator, fused HIP maps on GPU tensors
     utils                  paraGen / surveyGen / sourceGene / padding          (fwi_utils.py:11-140)
     obj_wrapper            SciPy L-BFGS-B glue                                 (obj_wrapper.py:10-97)
+    propagator             Model / Survey / ElasticPropagator, the non-autograd caller (propagator.py:8-226, survey.py:3-38)
     dist                   one-process-per-GPU shot sharding + RCCL all-reduce
 
 Device side: libsepfwi.so (csrc/, C ABI in include/sepfwi.h), hand-written HIP for gfx950.

@@ -176,3 +176,44 @@ def test_rock_physics_modules_on_hip_tensors(tmp_path, hip_ops, cls_name, key):
         # (the yardstick uses the CPU run's media, so "cpu" shows the chain rule's own rounding, ~1e-7; torch's GPU kernels
         # produce media that differ in the last bit, and the propagator's gradient answers a 1-ulp change of the medium with
         # ~1e-5: measured 2.6e-5 (VRH) and 2e-4 (Gassmann) -- float32 conditioning of the problem, on either device)
+
+
+def test_elastic_propagator_equals_the_autograd_module(tmp_path, hip_ops):
+    """The reference's second caller (propagator.py:57-226: `ElasticPropagator.apply_forward / apply_gradient`, velocities in
+    km/s, chain rule by hand) against the autograd module `FWI` (m/s) on the same survey: same gathers on disk, same misfit,
+    gradients equal after the factor 1000 of the velocity unit; and `device=` (everything in HBM) equals the CPU-tensor way."""
+    from sepfwi import modules as M
+    from sepfwi.propagator import ElasticPropagator, Model, Survey
+    pb = P.make_problem(str(tmp_path / "a"), hetero=True, nSteps=150, nshots=2)
+    nz, nx, nPml = pb["opt"]["nz"], pb["opt"]["nx"], pb["nPml"]
+    sv = pb["survey"]
+    survey = Survey(pb["para"]["f0"], np.array([sv["shot%d" % i]["x_src"] for i in range(2)]), np.array([sv["shot%d" % i]["z_src"] for i in range(2)]),
+                    np.array(sv["shot0"]["x_rec"]), np.array(sv["shot0"]["z_rec"]))
+    km = lambda m: {"vp": m["vp"] / np.float32(1e3), "vs": m["vs"] / np.float32(1e3), "rho": m["rho"]}
+    exp = str(tmp_path / "b")
+    import os
+    os.makedirs(exp)
+    mk = lambda m: Model(nx, nz, pb["para"]["dx"], pb["para"]["dz"], pb["nSteps"], pb["para"]["dt"], nPml, m["vp"], m["vs"], m["rho"], exp)
+    ElasticPropagator(mk(km(pb["true"])), survey).apply_forward(ngpu=1)
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    for sid in range(2):       # the two callers leave the same observed gathers (moduli differ by float rounding of the unit change)
+        a = np.fromfile(os.path.join(exp, "Data", "Shot_ett%d.bin" % sid), dtype=np.float32)
+        b = np.fromfile(os.path.join(pb["data_dir"], "Shot_ett%d.bin" % sid), dtype=np.float32)
+        assert a.size == b.size and np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b)
+    f = [torch.tensor(pb["init"][k], requires_grad=True) for k in ("vp", "vs", "rho")]
+    fwi = M.FWI(f[0], f[1], f[2], pb["Stf"], pb["opt"])
+    loss = fwi(pb["Shot_ids"], ngpu=1)
+    loss.backward()
+    loss = loss.detach()
+    want = [fwi.Vp.grad.numpy() * 1e3, fwi.Vs.grad.numpy() * 1e3, fwi.Den.grad.numpy()]
+    outs = {}
+    for dev in (None, "cuda"):
+        outs[dev] = ElasticPropagator(mk(km(pb["true"])), survey, device=dev).apply_gradient(mk(km(pb["init"])), ngpu=1)
+        misfit, gvp, gvs, grho, gstf = outs[dev]
+        assert abs(float(misfit[0]) - float(loss)) <= 2e-4 * float(loss) and gstf.shape == (2, pb["nSteps"])
+        for g, w in zip((gvp, gvs, grho), want):   # interior cells: autograd folds the padding's gradient onto the edge cells, this caller crops
+            assert g.shape == (nz, nx) and np.abs(g - w)[1:-1, 1:-1].max() <= 5e-4 * np.abs(w[1:-1, 1:-1]).max()
+    assert outs[None][0] == outs["cuda"][0]
+    for a, b in zip(outs[None][1:], outs["cuda"][1:]):
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()

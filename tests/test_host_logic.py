@@ -327,3 +327,38 @@ def test_packed_observed_file_round_trip(tmp_path):
     para = os.path.join(d, "p.json")
     ft.paraGen(64, 64, 10.0, 10.0, nS, 1e-3, 10.0, 8, 0, para, os.path.join(d, "s.json"), os.path.join(d, "Data"), obs_pack_fname=pack)
     assert json.load(open(para))["obs_pack_fname"] == pack
+
+
+def test_elastic_propagator_operands_and_chain_rule(monkeypatch, tmp_path):
+    """The OO caller (propagator.py:57-226): moduli WITHOUT the 1e-6 (km/s velocities), replicate padding, one Ricker row per
+    source, the survey written as given, and the hand-written chain rule to (vp, vs, rho) on the cropped gradients."""
+    import sepfwi.ops as ops
+    from sepfwi.propagator import ElasticPropagator, Model, Propagator, Survey
+    fake = _FakeOps()
+    fake.obscalc = lambda *a: fake.calls.append(("obscalc",) + a)
+    monkeypatch.setattr(ops, "fwi_ops", fake)
+    rng = np.random.default_rng(3)
+    nz, nx, nPml, nt = 12, 14, 4, 10
+    vp = (3.0 + 0.2 * rng.random((nz, nx))).astype(np.float32)
+    vs = (vp / 1.8).astype(np.float32)
+    rho = (2400.0 + 50.0 * rng.random((nz, nx))).astype(np.float32)
+    model = Model(nx, nz, 10.0, 10.0, nt, 1e-3, nPml, vp, vs, rho, str(tmp_path))
+    survey = Survey(20.0, np.array([6, 12]), np.array([5, 5]), np.arange(5, 16), np.full(11, 13))
+    with pytest.raises(NotImplementedError):
+        Propagator(model, survey).apply_forward(None)
+    prop = ElasticPropagator(model, survey)
+    prop.apply_forward(ngpu=1)
+    tag, lam, mu, den, stf, ngpu, ids, pf = fake.calls.pop()
+    nPad = 32 - (nz + 2 * nPml) % 32
+    assert tag == "obscalc" and lam.shape == (nz + 2 * nPml + nPad, nx + 2 * nPml) and stf.shape == (2, nt) and ids.tolist() == [0, 1]
+    assert torch.allclose(lam[nPml:nPml + nz, nPml:nPml + nx], torch.tensor(rho * (vp ** 2 - 2 * vs ** 2)))
+    assert torch.equal(lam[0, :], lam[nPml, :]) and torch.equal(mu[:, 0], mu[:, nPml]) and torch.equal(den[-1, :], den[nPml + nz - 1, :])
+    para, srv = json.load(open(pf)), json.load(open(os.path.join(str(tmp_path), "survey_file.json")))
+    assert para["nz"] == lam.shape[0] and para["nPad"] == nPad and para["f0"] == 20.0 and srv["nShots"] == 2
+    assert srv["shot1"]["x_src"] == 12 and srv["shot0"]["z_rec"] == [13] * 11
+    misfit, gvp, gvs, grho, gstf = prop.apply_gradient(Model(nx, nz, 10.0, 10.0, nt, 1e-3, nPml, vp * 1.01, vs, rho, str(tmp_path)))
+    assert misfit.shape == (1,) and float(misfit[0]) == 3.5 and gvp.shape == (nz, nx) and gstf.shape == (2, nt)
+    vp1 = vp * np.float32(1.01)       # gL = 2, gM = -1, gD = 0.5 from the fake operator
+    np.testing.assert_allclose(gvp, 2 * rho * vp1 * 2.0, rtol=1e-6)
+    np.testing.assert_allclose(gvs, -4 * rho * vs * 2.0 + 2 * rho * vs * -1.0, rtol=1e-6)
+    np.testing.assert_allclose(grho, (vp1 ** 2 - 2 * vs ** 2) * 2.0 + vs ** 2 * -1.0 + 0.5, rtol=1e-5)
