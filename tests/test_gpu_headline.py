@@ -10,6 +10,7 @@
   properties, plus an oracle-checked cropped twin of the same model, spacing, time step and source.
 * BASELINE.json configs[2] (2000 x 1000, 4000 steps, forward + adjoint): one shot and all 32 shots against the CPU oracle at
   full size (round 3), the 32-shot call against the sum of its groups.
+* A grid 7.5 x the headline's (5600 x 2800) for a few steps against the oracle: launch geometry and offsets at size.
 """
 import hashlib
 import os
@@ -371,3 +372,43 @@ def test_headline_32_shots_match_oracle(tmp_path, hip_ops):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "headline32_vs_oracle.txt"), "w") as fp:
         fp.write("2000x1000x4000, 32 shots in one call, HIP path vs CPU oracle (tests/golden/oracle_headline32.npz): %r\n" % out)
+
+
+@pytest.mark.timeout(900)
+def test_grid_seven_times_the_headline_matches_oracle(tmp_path, oracle, hip_ops):
+    """5600 x 2800 cells (16.6 M with the layers, 7.5 x the headline grid: 66 MB per array, tile and frame indices far beyond
+    anything else in the suite), 16 time steps, two shots near the middle, forward + adjoint against the CPU oracle: the launch
+    geometry, XCD banding and 64-bit offsets at a size where a 32-bit slip or a mis-banded tile would show."""
+    from sepfwi import utils as ft
+    nz, nx, nS = 2800, 5600, 16
+    stf = ft.sourceGene(25.0, 64, 1e-3)[34:34 + nS]          # the wavelet's main lobe inside the 16 steps
+    pb = P.make_problem(str(tmp_path), nz=nz, nx=nx, nPml=32, nSteps=nS, nshots=2, hetero=True, seed=5, src_z=1400,
+                        src_x=[2790, 2830], rec_z=1404, rec_x=list(range(2760, 2860)), stf=stf)
+    lt, mt, dt_ = pb["lame_true"]
+    # the trial medium differs from the observed one AT the source (the anomalies of make_problem are out of reach in 16 steps)
+    lam, mu, den = [(t * f).contiguous() for t, f in zip(pb["lame_init"], (0.92, 0.95, 1.03))]
+    obs = oracle.cufd(lt.numpy(), mt.numpy(), dt_.numpy(), pb["Stf"].numpy(), 2, pb["Shot_ids"].numpy(), pb["para"], pb["survey"])["syn"]
+    ref = oracle.cufd(lam.numpy(), mu.numpy(), den.numpy(), pb["Stf"].numpy(), 1, pb["Shot_ids"].numpy(), pb["para"], pb["survey"], obs=obs)
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    for i in range(2):
+        got = ft.read_shot_gather(pb["data_dir"], "ett", i, nS)
+        assert np.abs(obs[i, 3]).max() > 0 and P.rel_l2(got, obs[i, 3]) <= 1e-4, (i, P.rel_l2(got, obs[i, 3]))
+        obs[i, 3].tofile(os.path.join(pb["data_dir"], "Shot_ett%d.bin" % i))
+    hip_ops.release()
+    m, gL, gM, gD, gS = hip_ops.backward(lam.cuda(), mu.cuda(), den.cuda(), pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    assert abs(float(m) - ref["misfit"]) <= 1e-4 * abs(ref["misfit"]) and ref["misfit"] > 0
+    lines = []
+    for name, g, r in (("gLambda", gL, ref["gLambda"]), ("gMu", gM, ref["gMu"]), ("gDen", gD, ref["gDen"])):
+        g = g.cpu().numpy()
+        e, emax = P.rel_l2(g, r), np.abs(g - r).max() / np.abs(r).max()
+        lines.append("%s rel-L2 %.2e max %.2e nonzero cells %d" % (name, e, emax, np.count_nonzero(r)))
+        assert np.abs(r).max() > 0 and e <= 1e-3 and emax <= 1e-3, lines[-1]
+        odd = (g != 0) != (r != 0)      # the fringe of the stencil's light cone: values that underflow on one side only
+        assert np.abs(g[odd]).max(initial=0.0) <= 1e-12 * np.abs(r).max() and np.abs(r[odd]).max(initial=0.0) <= 1e-12 * np.abs(r).max(), name
+        far = np.ones(r.shape, bool)
+        far[1400 + 32 - 80:1400 + 32 + 80, 2760 + 32 - 80:2860 + 32 + 80] = False
+        assert not g[far].any(), name   # and nothing anywhere else on the 16.3 M cells
+    assert P.rel_l2(gS.numpy()[:2], ref["gStf"]) <= 1e-3
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "big_grid_vs_oracle.txt"), "w") as fp:
+        fp.write("5600 x 2800 x 16 steps, 2 shots, HIP vs CPU oracle: misfit %.6e vs %.6e\n" % (float(m), ref["misfit"]) + "\n".join(lines) + "\n")
