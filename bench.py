@@ -328,7 +328,7 @@ def main():
                 kern = "whole forward time step (k_stress<FWD> + k_velocity<FWD>)"
                 traffic = None
             out = {
-                "metric": "Gcell-updates/s (fwd+adj), 2000x1000 grid x 4000 steps" if args.mode == "fwdadj" else "Gcell-updates/s (fwd)",
+                "metric": "Gcell-updates/s (fwd+adj), %dx%d grid x %d steps" % (args.nx, args.nz, args.nsteps) if args.mode == "fwdadj" else "Gcell-updates/s (fwd)",
                 "value": round(value, 4), "unit": "Gcell-updates/s", "n_gpus": world, "steps": K, "warmup": W,
                 "ms_per_step": round(el * 1e3 / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
