@@ -74,7 +74,10 @@ def main():
     ap.add_argument("--nsteps", type=int, default=4000)
     ap.add_argument("--no-bounds", action="store_true",
                     help="run unconstrained like the reference's experiments (on this synthetic start the first steps then leave the\n"
-                         "Courant limit); with bounds SciPy spends 10-20 s per minimize() call turning 6 M bounds into Python lists")
+                         "Courant limit)")
+    ap.add_argument("--scipy-minimize", action="store_true",
+                    help="go through optimize.minimize() as the reference's scripts do instead of sepfwi.obj_wrapper.minimize_lbfgsb\n"
+                         "(same routine, same iterates; 10-20 s more per call on 6 M bounded unknowns)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,9 +146,13 @@ def main():
         if rank == 0:
             print("iterate %d: misfit %.6e   elapsed %.1f s" % (len(hist) - 1, obj.f, time.perf_counter() - t0), flush=True)
 
-    res = optimize.minimize(lambda x: c * timed_fun(x), obj.x0, method="L-BFGS-B", jac=lambda x: c * jac(x), bounds=obj.bounds,
-                            tol=None, callback=cb,
-                            options={"gtol": 1e-16, "maxiter": a.niter, "ftol": 1e-12, "maxcor": 5, "maxfun": 1500, "maxls": 6})
+    lb_opts = {"gtol": 1e-16, "maxiter": a.niter, "ftol": 1e-12, "maxcor": 5, "maxfun": 1500, "maxls": 6}
+    if a.scipy_minimize:
+        res = optimize.minimize(lambda x: c * timed_fun(x), obj.x0, method="L-BFGS-B", jac=lambda x: c * jac(x), bounds=obj.bounds,
+                                tol=None, callback=cb, options=lb_opts)
+    else:       # the same compiled L-BFGS-B routine and the same iterates, without SciPy's per-element loops over the bounds
+        from sepfwi.obj_wrapper import minimize_lbfgsb
+        res = minimize_lbfgsb(lambda x: c * timed_fun(x), obj.x0, lambda x: c * jac(x), bounds=obj.bounds, callback=cb, **lb_opts)
     wall = time.perf_counter() - t0
     if rank == 0:
         n_c = pb["n_c"]

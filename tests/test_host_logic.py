@@ -362,3 +362,41 @@ def test_elastic_propagator_operands_and_chain_rule(monkeypatch, tmp_path):
     np.testing.assert_allclose(gvp, 2 * rho * vp1 * 2.0, rtol=1e-6)
     np.testing.assert_allclose(gvs, -4 * rho * vs * 2.0 + 2 * rho * vs * -1.0, rtol=1e-6)
     np.testing.assert_allclose(grho, (vp1 ** 2 - 2 * vs ** 2) * 2.0 + vs ** 2 * -1.0 + 0.5, rtol=1e-5)
+
+
+def test_lean_lbfgsb_driver_gives_scipys_iterates_bit_for_bit():
+    """sepfwi.obj_wrapper.minimize_lbfgsb drives SciPy's compiled L-BFGS-B routine itself (vectorised bound codes instead of
+    optimize.minimize's per-element Python loops): same iterates, evaluations, message -- with every kind of bound in play."""
+    from scipy import optimize
+    from sepfwi.obj_wrapper import minimize_lbfgsb
+    rng = np.random.default_rng(0)
+    n = 60
+
+    def fun(x):
+        return float(np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+
+    def jac(x):
+        g = np.zeros_like(x)
+        g[:-1] = -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return g
+
+    x0 = rng.uniform(-2, 2, n)
+    lb, ub = np.full(n, -np.inf), np.full(n, np.inf)
+    lb[::3] = -0.5; ub[1::3] = 0.8; lb[2::6] = 0.1; ub[2::6] = 0.7      # lower-only, upper-only, boxed, free
+    B = optimize.Bounds(lb, ub)
+    for opts in (dict(maxiter=40, maxcor=5, ftol=1e-12, gtol=1e-16, maxfun=1500, maxls=20), dict(maxiter=500, maxcor=7, ftol=1e-9, gtol=1e-6, maxfun=60, maxls=20)):
+        h1, h2 = [], []
+        r1 = optimize.minimize(fun, x0, method="L-BFGS-B", jac=jac, bounds=B, callback=lambda x: h1.append(x.copy()), options=opts)
+        r2 = minimize_lbfgsb(fun, x0, jac, bounds=B, callback=lambda x: h2.append(x.copy()), **opts)
+        assert (r1.nit, r1.nfev, r1.status, r1.message, r1.fun) == (r2.nit, r2.nfev, r2.status, r2.message, r2.fun)
+        assert len(h1) == len(h2) and all(np.array_equal(a, b) for a, b in zip(h1, h2))
+        assert np.array_equal(r1.x, r2.x) and np.array_equal(r1.jac, r2.jac) and np.all(r2.x >= lb) and np.all(r2.x <= ub)
+        v = rng.standard_normal(n)
+        assert np.array_equal(r1.hess_inv.matvec(v), r2.hess_inv.matvec(v))
+    def stop(x):
+        raise StopIteration
+    assert minimize_lbfgsb(fun, x0, jac, bounds=B, callback=stop).nit == 1
+    assert minimize_lbfgsb(fun, x0, jac, bounds=None, maxiter=5).nit == 5          # no bounds: the public route
+    with pytest.raises(ValueError):
+        minimize_lbfgsb(fun, x0, jac, bounds=optimize.Bounds(np.ones(n), np.zeros(n)))
