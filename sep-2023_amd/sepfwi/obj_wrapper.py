@@ -68,7 +68,7 @@ _SETULB_SIGNATURE = "setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,lsave,isave,
 def minimize_lbfgsb(fun, x0, jac, bounds=None, callback=None, maxiter=15000, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5,
                     maxfun=15000, maxls=20):
     """`optimize.minimize(fun, x0, method="L-BFGS-B", jac=jac, bounds=bounds, callback=callback, options={...})` -- what the
-    reference's experiment scripts call (Main-001-FWI-Anomaly-Vp-Vs-Den.py:183-195) -- with the same compiled routine
+    reference's experiment scripts call (Main-001-FWI-Anomaly-Vp-Vs-Den.py:157-168) -- with the same compiled routine
     (`scipy.optimize._lbfgsb.setulb`) driven directly, so the iterates are the same bit for bit, but without SciPy's
     per-element Python loops over the bounds: on the 6 M unknowns of a 2000 x 1000 model those cost 10-20 s per minimize() call
     (new-style -> old-style -> new-style conversions and a dict look-up per variable), the one serial term of a multi-GPU
