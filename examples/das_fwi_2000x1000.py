@@ -78,14 +78,19 @@ def main():
     ap.add_argument("--scipy-minimize", action="store_true",
                     help="go through optimize.minimize() as the reference's scripts do instead of sepfwi.obj_wrapper.minimize_lbfgsb\n"
                          "(same routine, same iterates; 10-20 s more per call on 6 M bounded unknowns)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend under torchrun (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0: rehearsal of the N-rank run on a one-GPU box (with --backend gloo)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend="gloo")
     rank = fdist.rank()
     dev = torch.device("cuda", local)
     fwi_ops.device_override = local
