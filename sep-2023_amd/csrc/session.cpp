@@ -13,7 +13,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -75,11 +74,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         throw std::invalid_argument("parameter file: if_src_update together with if_cross_misfit is not supported");
     cond_on_ = par.if_win || par.has_filter || par.if_cross_misfit || par.if_src_update;
     HIP_OK(hipSetDevice(gpu_id_));
-    {   // probe hook (scripts/prio_probe.py): SEPFWI_STREAM_PRIO=low puts every stream of this session at the lowest priority
-        const char *pr = std::getenv("SEPFWI_STREAM_PRIO");
-        low_prio_ = pr && std::string(pr) == "low";
-    }
-    make_stream(&own_stream_);
+    HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
     for (auto &e : ev_) HIP_OK(hipEventCreate(&e));
     for (auto &e : probe_ev_) HIP_OK(hipEventCreate(&e));
@@ -242,23 +237,13 @@ Session::~Session() {
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
-void Session::make_stream(hipStream_t *st) {
-    if (low_prio_) {
-        int least = 0, greatest = 0;
-        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_OK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, least));
-    } else {
-        HIP_OK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-    }
-}
-
 // Extra lanes of forward state (fields, memory variables, boundary frames, seismograms, residual) and their streams.
 void Session::ensure_lanes(int n_lanes, bool with_frames) {
     const size_t n = cells_;
     for (int k = 1; k < n_lanes && k < kMaxLanes; k++) {
         XLane &L = xl_[k];
         if (!L.stream) {
-            make_stream(&L.stream);
+            HIP_OK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
             HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
         }
         if (!L.state) {

@@ -46,8 +46,6 @@ class Session {
     template <class T> T *dalloc(size_t n);
     const float *observed_ett(int shot_id, int nrec, hipStream_t st);
     long long pack_offset(int shot_id, int nrec);
-    void make_stream(hipStream_t *st);
-    bool low_prio_ = false;
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void order_after_null_stream(hipStream_t st);
