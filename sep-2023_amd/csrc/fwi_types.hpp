@@ -36,7 +36,6 @@ struct Grid {
     int rk_lazy;  // 1: adjoint kernels read 1/K only inside the layers
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
     int amu_fly;  // 1: the 4-point harmonic mean of mu recomputed from mu in the stress-type kernels
-    int skew;  // k_bwd_a / k_bwd_b: tiles by which the bands of the even XCDs are longer and those of the odd ones shorter (experiment)
     int nb, shot_fastest;  // batched launches: shots per grid and the order of (tile, shot) in the block index
 };
 

@@ -87,24 +87,6 @@ __device__ __forceinline__ Cell my_cell(const Grid &g, int *shot = nullptr) {
     return c;
 }
 
-// Tile of a block of the two backward kernels with UNEQUAL bands (option xcd_skew, experiment).  The XCDs do not run at one speed:
-// in a launch of k_bwd_a / k_bwd_b they finish 1.5 - 3 us apart (of 26 - 29; scripts/timeline_probe.py), the odd-numbered ones
-// later than the even-numbered ones in every sample, and with equal bands the launch lasts as long as the slowest.  Here the
-// even XCDs' bands are g.skew tiles longer and the odd ones' as much shorter; the surplus blocks of the odd XCDs leave at once.
-__device__ __forceinline__ bool skew_cell(const Grid &g, Cell &c) {
-    const int q = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int per = (g.gx * g.gy + 7) >> 3;
-    const int odd = q & 1;
-    if (j >= per + (odd ? -g.skew : g.skew)) return false;
-    const int t = q * per + (odd ? g.skew : 0) + j;
-    const int ty = t / g.gx, tx = t - ty * g.gx;
-    c.x = tx * BX + (threadIdx.x & (BX - 1));
-    c.z = __builtin_amdgcn_readfirstlane(ty * g.bz + (int)(threadIdx.x >> 6));
-    if (ty >= g.gy) c.z = g.nz + 1;  // surplus tile of the padded numbering: out of range
-    c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
-    return true;
-}
-
 // 4-point harmonic mean of mu at the staggered corner (z+1/2, x+1/2): aveMuInit, utilities.cu:124-137.  amu_fly: rebuilt
 // from mu (three neighbour taps that hit the cache) instead of streaming a second array; single precision with the
 // hardware reciprocal (<= 1 ulp each), i.e. within 4e-7 of the reference's double-precision value.  While the option is
@@ -584,88 +566,45 @@ __device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int
                    cx, cx + nx,  cx + 2 * nx,  cx + 3 * nx,  cx + 4 * nx,  cx + 5 * nx};
 }
 
-// Probe build only (-DSEPFWI_TIMELINE, scripts/timeline_probe.py): every wave of the two backward kernels leaves its start and end
-// time (100 MHz s_memrealtime, after its last store has been acknowledged) and the XCD it ran on; the last launch's record is
-// read back through sepfwi_probe_timeline.  Not compiled into the product.
-#ifdef SEPFWI_TIMELINE
-constexpr int TL_MAX = 1 << 17;
-__device__ unsigned long long g_tl[2][TL_MAX][2];
-__device__ unsigned g_tl_xcc[2][TL_MAX];
-#define TL_BEGIN const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
-#define TL_END(K)                                                                                   \
-    {                                                                                               \
-        __builtin_amdgcn_s_waitcnt(0);                                                              \
-        const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                          \
-        if ((threadIdx.x & 63) == 0 && w < TL_MAX) {                                                \
-            g_tl[K][w][0] = tl0;                                                                    \
-            g_tl[K][w][1] = __builtin_amdgcn_s_memrealtime();                                       \
-            g_tl_xcc[K][w] = __builtin_amdgcn_s_getreg(20 | (3 << 11)); /* HW_REG_XCC_ID, 4 bits */ \
-        }                                                                                           \
-    }
-#else
-#define TL_BEGIN
-#define TL_END(K)
-#endif
-
-template <bool EARLY, bool STEAL>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *__restrict__ frame_t) {
-    TL_BEGIN
-    auto cell = [&](const BwdArgs &b, const Cell &c) {
-        const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
-        const PmlMem m = mem_of(b.mem, b.n);
-        const Media md = media_of(b.media, b.n);
-        const ImgAcc acc = acc_of(b.acc, b.n);
-        const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
-        if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
-            const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-            velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
-            stress_adj_apply(q, g, c, adj, m, md, pc);
-        } else {
-            velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
-            stress_adj_body(g, c, adj, m, md, pc);
-        }
-    };
-    if constexpr (STEAL) {
-        Cell c;
-        if (!skew_cell(g, c)) return;
-        cell(b, c);
+    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    const PmlMem m = mem_of(b.mem, b.n);
+    const Media md = media_of(b.media, b.n);
+    const ImgAcc acc = acc_of(b.acc, b.n);
+    const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
+    const Cell c = my_cell(g);
+    if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
+        const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        cell(b, my_cell(g));
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        stress_adj_body(g, c, adj, m, md, pc);
     }
-    TL_END(0)
 }
-template <bool EARLY, bool STEAL>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__restrict__ frame_t, int zx_src /* z<<16 | x */,
                                                 float src_amp, float src_rxz, float *__restrict__ stf_grad_it,
                                                 int lr_zx /* z<<16 | x0 */, int lr_n, const float *__restrict__ lr_res) {
-    TL_BEGIN
     const int z_src = zx_src >> 16, x_src = zx_src & 0xffff;
     const LineRec lr{lr_zx >> 16, lr_zx & 0xffff, lr_n, nullptr, nullptr, nullptr, lr_res};
-    auto cell = [&](const BwdArgs &b, const Cell &c) {
-        const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
-        const PmlMem m = mem_of(b.mem, b.n);
-        const Media md = media_of(b.media, b.n);
-        const ImgAcc acc = acc_of(b.acc, b.n);
-        const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
-        // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
-        if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
-        if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
-            const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-            stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
-            velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
-        } else {
-            stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
-            velocity_adj_body(g, c, adj, m, md, pc, lr);
-        }
-    };
-    if constexpr (STEAL) {
-        Cell c;
-        if (!skew_cell(g, c)) return;
-        cell(b, c);
+    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    const PmlMem m = mem_of(b.mem, b.n);
+    const Media md = media_of(b.media, b.n);
+    const ImgAcc acc = acc_of(b.acc, b.n);
+    const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
+    const Cell c = my_cell(g);
+    // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
+    if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
+    if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
+        const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        cell(b, my_cell(g));
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        velocity_adj_body(g, c, adj, m, md, pc, lr);
     }
-    TL_END(1)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -996,7 +935,6 @@ const OptField kOptFields[] = {
     {"batch_order", &KernelOptions::batch_order, 0, 1},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
-    {"steal", &KernelOptions::steal, 0, 50},
 };
 }  // namespace
 
@@ -1029,17 +967,8 @@ static inline Grid tiled(const Grid &g0, const KernelOptions &o, int fly_bit = -
     g.rho_fly = fly_bit < 0 ? 0 : (o.rho_fly >> fly_bit) & 1;
     g.amu_fly = fly_bit < 0 ? 0 : (o.amu_fly >> fly_bit) & 1;
     g.rk_lazy = o.rk_lazy;
-    g.skew = 0;
     return g;
 }
-// dynamic tail of the two backward kernels: needs the XCD-banded numbering; per cent of a band -> tiles
-static inline Grid tiled_steal(const Grid &g0, const KernelOptions &o) {
-    Grid g = tiled(g0, o, 1);
-    const int per = (g.gx * g.gy + 7) / 8;
-    g.skew = g.xcd_remap ? (int)((long long)per * o.steal / 1000) : 0;   // per mille of a band
-    return g;
-}
-static inline dim3 steal_grid(const Grid &g) { return dim3(8 * ((g.gx * g.gy + 7) / 8 + g.skew)); }
 static inline dim3 field_grid(const Grid &g) {
     const int nb = g.gx * g.gy;
     return dim3(g.xcd_remap ? ((nb + 7) / 8) * 8 : nb);
@@ -1095,25 +1024,23 @@ void launch_stress_adj(hipStream_t st, const Grid &g0, const KernelOptions &o, F
 
 void launch_bwd_a(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
                   const float *frame_t, Fields adj, ImgAcc acc) {
-    const Grid g = tiled_steal(g0, o);
+    const Grid g = tiled(g0, o, 1);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    const bool steal = g.skew > 0;
-    auto k = (o.early & 1) ? (steal ? k_bwd_a<true, true> : k_bwd_a<true, false>) : (steal ? k_bwd_a<false, true> : k_bwd_a<false, false>);
-    hipLaunchKernelGGL(k, steal ? steal_grid(g) : field_grid(g), BLOCK, 0, st, g, b, frame_t);
+    auto k = (o.early & 1) ? k_bwd_a<true> : k_bwd_a<false>;
+    hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
 
 void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
                   int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
                   hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const Grid g = tiled_steal(g0, o);
+    const Grid g = tiled(g0, o, 1);
     const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    const bool steal = g.skew > 0;
-    auto k = (o.early & 2) ? (steal ? k_bwd_b<true, true> : k_bwd_b<true, false>) : (steal ? k_bwd_b<false, true> : k_bwd_b<false, false>);
+    auto k = (o.early & 2) ? k_bwd_b<true> : k_bwd_b<false>;
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
-        hipExtLaunchKernelGGL(k, steal ? steal_grid(g) : field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t,
-                              (z_src << 16) | x_src, src_amp, src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
+        hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
+                              src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
     else
-        hipLaunchKernelGGL(k, steal ? steal_grid(g) : field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
+        hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
@@ -1206,13 +1133,3 @@ void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc a
 }
 
 }  // namespace sepfwi
-
-#ifdef SEPFWI_TIMELINE
-// probe build only: the wave timeline of the last k_bwd_a / k_bwd_b launch (see TL_BEGIN / TL_END)
-extern "C" int sepfwi_probe_timeline(unsigned long long *times /* [2][TL_MAX][2] */, unsigned *xcc /* [2][TL_MAX] */) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(times, HIP_SYMBOL(sepfwi::g_tl), sizeof(sepfwi::g_tl)) != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(xcc, HIP_SYMBOL(sepfwi::g_tl_xcc), sizeof(sepfwi::g_tl_xcc)) != hipSuccess) return -1;
-    return sepfwi::TL_MAX;
-}
-#endif

@@ -25,9 +25,6 @@ struct KernelOptions {
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
-    int steal = 0;        // k_bwd_a / k_bwd_b: per cent of every XCD's band of tiles that is NOT assigned statically but handed out wave-row
-                          // by wave-row from eight atomic counters (own band's tail first, then the other XCDs'): XCDs that finish
-                          // early take over the tail of the slow ones (scripts/timeline_probe.py: they end 1.5-3 us apart)
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)
 };

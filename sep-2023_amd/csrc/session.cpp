@@ -111,7 +111,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     media_ = dalloc<float>(6 * n);
     HIP_OK(hipMemset(media_, 0, 6 * n * sizeof(float)));
     md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n};
-    acc_buf_ = dalloc<float>(5 * n + 32);  // + the tile-pool counters of k_bwd_a / k_bwd_b (kernels.hip, option steal)
+    acc_buf_ = dalloc<float>(5 * n);
     acc_ = ImgAcc{acc_buf_, acc_buf_ + n, acc_buf_ + 2 * n, acc_buf_ + 3 * n, acc_buf_ + 4 * n};
     const size_t dense = (size_t)par.nz * (size_t)par.nx;
     in_stage_ = dalloc<float>(3 * dense);
@@ -517,7 +517,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         HIP_OK(hipMalloc((void **)&frame_, fb));
         device_bytes_ += (long long)fb;
     }
-    if (withAdj) HIP_OK(hipMemsetAsync(acc_buf_, 0, (5 * n + 32) * sizeof(float), st));  // Model.cu:68-71 (+ the pool counters)
+    if (withAdj) HIP_OK(hipMemsetAsync(acc_buf_, 0, 5 * n * sizeof(float), st));  // Model.cu:68-71
     if (if_res) HIP_OK(hipMemsetAsync(scal_, 0, 4 * sizeof(double), st));
 
     // ---- source traces on the host: row shot_ids[i] of stf, tapered (Src_Rec.cu:130-137) ----
