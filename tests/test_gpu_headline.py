@@ -331,16 +331,17 @@ def test_headline_32_shots_match_oracle(tmp_path, hip_ops):
     grad checked vs reference" -- ONE 32-shot call of the HIP path against the CPU oracle's 32 shots (0.9e12 cell-updates on
     the host, scripts/make_golden_headline32.py; per-shot float32 gradients summed in float64).  Observed data: modelled by
     this library (the oracle's 1 GB of gathers are not committed; the single-shot test compares them channel by channel)."""
-    if not os.path.exists(HEADLINE32_GOLDEN):
+    golden = os.environ.get("SEPFWI_GOLDEN32_PARTIAL", HEADLINE32_GOLDEN)    # a partial file (first N shots) for a dry run
+    if not os.path.exists(golden):
         pytest.skip("tests/golden/oracle_headline32.npz not generated (scripts/make_golden_headline32.py, about 3 hours of CPU)")
     sys.path.insert(0, ROOT)
     import bench
     import scripts.make_golden_headline32 as mg
     from sepfwi import utils as ft
-    G = np.load(HEADLINE32_GOLDEN)
-    nS, n_shots = mg.NSTEPS, mg.NSHOTS
-    assert int(G["n_shots"]) == n_shots
-    pb = bench.setup_problem(str(tmp_path), mg.NZ, mg.NX, nS, n_shots)
+    G = np.load(golden)
+    nS, n_shots = mg.NSTEPS, int(G["n_shots"])
+    assert n_shots == mg.NSHOTS or golden != HEADLINE32_GOLDEN
+    pb = bench.setup_problem(str(tmp_path), mg.NZ, mg.NX, nS, mg.NSHOTS)
     assert mg.digest(pb) == str(G["digest"]), "bench.py's problem generator drifted: regenerate with scripts/make_golden_headline32.py"
     lt, mt, dt_ = [t.cuda() for t in pb["lame_true"]]
     lam, mu, den = [t.cuda() for t in pb["lame_init"]]
@@ -366,12 +367,12 @@ def test_headline_32_shots_match_oracle(tmp_path, hip_ops):
                     abs(np.linalg.norm(g.astype(np.float64)) - float(G[key + "_norm"])) / float(G[key + "_norm"]))
         assert max(out[key]) <= 1e-3, (key, out[key])
         assert np.abs(dec - G[key + "_dec"]).max() <= 1e-3 * gmax and np.abs(win - G[key + "_win"]).max() <= 1e-3 * gmax, key
-    out["gStf"] = P.rel_l2(gS.numpy(), G["gStf"])
+    out["gStf"] = P.rel_l2(gS.numpy()[:n_shots], G["gStf"])
     assert out["gStf"] <= 1e-3, out
     print("32-shot call vs the oracle's 32 shots: misfit rel, (rel-L2 every 8th cell, window, rel norm) per gradient, gStf:", out)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "headline32_vs_oracle.txt"), "w") as fp:
-        fp.write("2000x1000x4000, 32 shots in one call, HIP path vs CPU oracle (tests/golden/oracle_headline32.npz): %r\n" % out)
+        fp.write("2000x1000x4000, %d shots in one call, HIP path vs CPU oracle (%s): %r\n" % (n_shots, os.path.basename(golden), out))
 
 
 @pytest.mark.timeout(900)
