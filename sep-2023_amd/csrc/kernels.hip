@@ -878,12 +878,17 @@ __global__ void k_finalize_gradients(Grid g, Media md, ImgAcc acc, float *__rest
             gl = (float)((double)acc.lam[i] * 1e6);
             gm = (float)((double)acc.mu[i] * 1e6);
         }
+        // A fluid cell (mu = 0) makes every corner around it a zero-average one, which sprays nothing (el_stress.cu:112: the spray
+        // is inside `if (ave_Mu != 0)`); its 1/mu^2 = inf must not meet those zero weights (inf * 0 = NaN).
         const double rmu2 = 1.0 / ((double)md.mu[i] * (double)md.mu[i]);
-        float s;
-        s = xz_weight(g, md, acc, z, x);          gm += (float)(rmu2 * (double)s);   // own corner
-        s = xz_weight(g, md, acc, z - 1, x);      gm += (float)(rmu2 * (double)s);   // sprayed down (z+1<=zmax holds: target z<=zmax)
-        s = xz_weight(g, md, acc, z, x - 1);      gm += (float)(rmu2 * (double)s);   // sprayed right, unconditional
-        if (inside) { s = xz_weight(g, md, acc, z - 1, x - 1); gm += (float)(rmu2 * (double)s); }
+        auto spray = [&](int pz, int px) {
+            const float s = xz_weight(g, md, acc, pz, px);
+            if (s != 0.0f) gm += (float)(rmu2 * (double)s);
+        };
+        spray(z, x);          // own corner
+        spray(z - 1, x);      // sprayed down (z+1<=zmax holds: target z<=zmax)
+        spray(z, x - 1);      // sprayed right, unconditional
+        if (inside) spray(z - 1, x - 1);
         // density
         auto A = [&](int pz, int px) -> float {
             if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
