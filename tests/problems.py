@@ -19,7 +19,7 @@ def smooth_random(rng, shape, lo, hi, passes=8):
 
 def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, dt=1.0e-3, f0=25.0,
                  hetero=True, seed=7, rec_z=None, src_z=2, nrec_stride=1, nPad=None, src_x=None, das_fiber="horizontal",
-                 rec_x=None, stf=None, das_sensitivity=None):
+                 rec_x=None, stf=None, das_sensitivity=None, dz=None):
     """Writes para/survey JSON under workdir and returns everything a test needs.
     Models: `true` (with anomalies) and `init` (smooth), both (nz, nx) float32, plus padded versions."""
     rng = np.random.default_rng(seed)
@@ -47,7 +47,7 @@ def make_problem(workdir, nz=44, nx=60, nPml=10, nSteps=240, nshots=2, dh=10.0, 
     para_fname = os.path.join(workdir, "para_file.json")
     survey_fname = os.path.join(workdir, "survey_file.json")
     data_dir = os.path.join(workdir, "Data")
-    ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir, das_fiber=das_fiber)
+    ft.paraGen(nz_pad, nx_pad, dh if dz is None else dz, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir, das_fiber=das_fiber)
     src_x = np.linspace(6, nx - 7, nshots).round().astype(int) if src_x is None else np.asarray(src_x, dtype=int)
     src_zs = np.full(nshots, src_z, dtype=int)
     rec_x = np.arange(4, nx - 4, nrec_stride).astype(int) if rec_x is None else np.asarray(rec_x, dtype=int)
