@@ -78,7 +78,8 @@ int sepfwi_cufd(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_D
 
 /* Same as sepfwi_cufd, but all launches go to `hip_stream` (a hipStream_t, may be NULL) and the call
  * returns without a final device synchronisation when `async` != 0 and every output pointer is a
- * device pointer (misfit, gradients).  Used by bench.py to time with inputs resident in HBM. */
+ * device pointer (misfit, gradients); the caller then synchronises its stream before it reads them
+ * (tests/test_gpu_parity.py::test_c_abi_on_a_caller_stream_without_final_synchronisation). */
 int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den,
                        float *grad_stf, const float *Lambda, const float *Mu, const float *Den,
                        const float *stf, int calc_id, int gpu_id, int group_size,
