@@ -217,3 +217,28 @@ def test_elastic_propagator_equals_the_autograd_module(tmp_path, hip_ops):
     assert outs[None][0] == outs["cuda"][0]
     for a, b in zip(outs[None][1:], outs["cuda"][1:]):
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+
+
+def test_only_one_field_inverted_on_hip_tensors(tmp_path, hip_ops):
+    """Main-004-FWI-Rock-Physics.py:117-119 inverts one field of three (the others without requires_grad).  On HIP tensors the fused
+    map then has two constant inputs: its gradient for the inverted field is the corresponding block of the all-fields gradient,
+    through the real operator, and the SciPy glue sees a vector of that one field."""
+    from sepfwi import modules as M
+    from sepfwi.obj_wrapper import PyTorchObjective
+    pb = P.make_problem(str(tmp_path), hetero=True, nSteps=120, nshots=2)
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    T = lambda k, g: torch.tensor(pb["init"][k], device="cuda", requires_grad=g)
+    full = M.FWI(T("vp", True), T("vs", True), T("rho", True), pb["Stf"], pb["opt"])
+    assert full._fusable()
+    f_full = full(pb["Shot_ids"], ngpu=1)
+    f_full.backward()
+    for which, name in (("vp", "Vp"), ("vs", "Vs"), ("rho", "Den")):
+        part = M.FWI(T("vp", which == "vp"), T("vs", which == "vs"), T("rho", which == "rho"), pb["Stf"], pb["opt"])
+        assert part._fusable() and [n for n, _ in part.named_parameters()] == [name]
+        obj = PyTorchObjective(part, lambda: part(pb["Shot_ids"], ngpu=1))
+        fun, jac = obj.fun, obj.jac
+        assert obj.x0.size == pb["init"]["vp"].size and fun(obj.x0) == float(f_full.detach())
+        g = jac(obj.x0).reshape(pb["init"]["vp"].shape)
+        w = getattr(full, name).grad.cpu().numpy().astype(np.float64)
+        assert np.abs(g - w).max() <= 1e-6 * np.abs(w).max(), name

@@ -400,3 +400,27 @@ def test_lean_lbfgsb_driver_gives_scipys_iterates_bit_for_bit():
     assert minimize_lbfgsb(fun, x0, jac, bounds=None, maxiter=5).nit == 5          # no bounds: the public route
     with pytest.raises(ValueError):
         minimize_lbfgsb(fun, x0, jac, bounds=optimize.Bounds(np.ones(n), np.zeros(n)))
+
+
+def test_only_some_fields_inverted(monkeypatch, tmp_path):
+    """The rock-physics experiments invert ONE of the three fields (Main-004-FWI-Rock-Physics.py:117-119: PHI and CC without
+    requires_grad, SW with): the fixed ones are plain attributes, not parameters, SciPy's vector holds the inverted field only,
+    and its gradient is the corresponding block of the all-fields gradient."""
+    import sepfwi.ops as ops
+    from sepfwi import modules as M
+    from sepfwi.obj_wrapper import PyTorchObjective
+    monkeypatch.setattr(ops, "fwi_ops", _FakeOps())
+    pb = P.make_problem(str(tmp_path), nz=12, nx=14, nPml=4, nSteps=10, nshots=1, nPad=3)
+    T = lambda k, g: torch.tensor(pb["init"][k], requires_grad=g)
+    full = M.FWI(T("vp", True), T("vs", True), T("rho", True), pb["Stf"], pb["opt"])
+    full(pb["Shot_ids"], ngpu=1).backward()
+    for which in ("vp", "vs", "rho"):
+        part = M.FWI(T("vp", which == "vp"), T("vs", which == "vs"), T("rho", which == "rho"), pb["Stf"], pb["opt"])
+        name = {"vp": "Vp", "vs": "Vs", "rho": "Den"}[which]
+        assert [n for n, _ in part.named_parameters()] == [name]
+        obj = PyTorchObjective(part, lambda: part(pb["Shot_ids"], ngpu=1))
+        assert obj.x0.size == 12 * 14
+        fun, jac = obj.fun, obj.jac
+        assert fun(obj.x0) == 3.5
+        g = jac(obj.x0).reshape(12, 14)
+        np.testing.assert_allclose(g, getattr(full, name).grad.numpy().astype(np.float64), rtol=1e-6)
