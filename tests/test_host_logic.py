@@ -424,3 +424,27 @@ def test_only_some_fields_inverted(monkeypatch, tmp_path):
         assert fun(obj.x0) == 3.5
         g = jac(obj.x0).reshape(12, 14)
         np.testing.assert_allclose(g, getattr(full, name).grad.numpy().astype(np.float64), rtol=1e-6)
+
+
+def test_coarse_parameter_grid_is_interpolated(monkeypatch, tmp_path):
+    """opt["nz_orig"], opt["nx_orig"] smaller than the modelling grid: the parameters live on the coarse grid and are resized
+    bilinearly before the replicate padding (fwi_utils.py:31-44; the reference's scripts always set them equal).  The operator
+    sees the padded fine grid, the gradient comes back on the coarse one, and the one-launch maps stand aside."""
+    import sepfwi.ops as ops
+    from sepfwi import modules as M
+    fake = _FakeOps()
+    monkeypatch.setattr(ops, "fwi_ops", fake)
+    pb = P.make_problem(str(tmp_path), nz=12, nx=14, nPml=4, nSteps=10, nshots=1, nPad=3)
+    opt = dict(pb["opt"], nz_orig=6, nx_orig=7)
+    coarse = lambda k: torch.tensor(np.ascontiguousarray(pb["init"][k][::2, ::2]), requires_grad=True)
+    fwi = M.FWI(coarse("vp"), coarse("vs"), coarse("rho"), pb["Stf"], opt)
+    assert not fwi._fusable()
+    loss = fwi(pb["Shot_ids"], ngpu=1)
+    loss.backward()
+    lam = fake.calls[0][0]
+    assert lam.shape == (pb["nz_pad"], pb["nx_pad"]) and fwi.Vp.grad.shape == (6, 7) and torch.isfinite(fwi.Vp.grad).all()
+    # a constant field stays that constant on the fine grid
+    c = lambda v: torch.full((6, 7), v, requires_grad=True)
+    fwi2 = M.FWI(c(3000.0), c(1700.0), c(2400.0), pb["Stf"], opt)
+    fwi2(pb["Shot_ids"], ngpu=1)
+    assert torch.allclose(fake.calls[1][2], torch.full((pb["nz_pad"], pb["nx_pad"]), 2400.0))
