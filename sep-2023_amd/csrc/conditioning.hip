@@ -239,6 +239,10 @@ Conditioner::Plans &Conditioner::plans_for(int nrec, hipStream_t st) {
         fft_ok(hipfftPlan1d(&b, 2 * nt_, HIPFFT_C2R, nrec), "hipfftPlan1d(C2R)");
         p.fwd = (void *)f;
         p.inv = (void *)b;
+        // Plan creation is not stream-ordered (rocFFT may build its tables with work of its own on the null stream), and the
+        // session's streams are non-blocking ones that do not wait for the null stream: make sure that work is complete
+        // before the plan's first use.  Once per trace count.
+        if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("conditioning: hipDeviceSynchronize failed");
         it = plans_.emplace(nrec, p).first;
     }
     fft_ok(hipfftSetStream((hipfftHandle)it->second.fwd, st), "hipfftSetStream");
