@@ -16,6 +16,7 @@
 #include <string>
 
 #include "conditioning.hpp"
+#include "device_alloc.hpp"
 
 namespace sepfwi {
 
@@ -183,8 +184,8 @@ void fft_ok(hipfftResult r, const char *what) {
 
 Conditioner::Conditioner(int nt, int max_nrec) : nt_(nt), cap_(max_nrec) {
     const size_t npad = 2 * (size_t)nt, nf = (size_t)nt + 1;
-    if (hipMalloc((void **)&pad_, npad * cap_ * sizeof(float)) != hipSuccess || hipMalloc((void **)&spec_, nf * cap_ * sizeof(hipfftComplex)) != hipSuccess ||
-        hipMalloc((void **)&norm_, 3 * (size_t)cap_ * sizeof(float)) != hipSuccess)
+    if (dev_malloc((void **)&pad_, npad * cap_ * sizeof(float)) != hipSuccess || dev_malloc((void **)&spec_, nf * cap_ * sizeof(hipfftComplex)) != hipSuccess ||
+        dev_malloc((void **)&norm_, 3 * (size_t)cap_ * sizeof(float)) != hipSuccess)
         throw std::runtime_error("conditioning: out of device memory");
 }
 
@@ -253,9 +254,9 @@ Conditioner::Plans &Conditioner::plans_for(int nrec, hipStream_t st) {
 void Conditioner::ensure_source_buffers() {
     if (pad2_) return;
     const size_t npad = 2 * (size_t)nt_, nf = (size_t)nt_ + 1;
-    if (hipMalloc((void **)&pad2_, npad * cap_ * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&spec2_, nf * cap_ * sizeof(hipfftComplex)) != hipSuccess ||
-        hipMalloc((void **)&coef_, nf * sizeof(hipfftComplex)) != hipSuccess)
+    if (dev_malloc((void **)&pad2_, npad * cap_ * sizeof(float)) != hipSuccess ||
+        dev_malloc((void **)&spec2_, nf * cap_ * sizeof(hipfftComplex)) != hipSuccess ||
+        dev_malloc((void **)&coef_, nf * sizeof(hipfftComplex)) != hipSuccess)
         throw std::runtime_error("conditioning: out of device memory (source update)");
     if (hipMemset(coef_, 0, nf * sizeof(hipfftComplex)) != hipSuccess) throw std::runtime_error("conditioning: hipMemset failed");
 }

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <stdexcept>
 
+#include "device_alloc.hpp"
 #include "kernels.hpp"
 
 namespace sepfwi {
@@ -56,7 +57,7 @@ static std::string shot_file(const Params &p, int comp, int id) {
 template <class T>
 T *Session::dalloc(size_t n) {
     void *p = nullptr;
-    HIP_OK(hipMalloc(&p, n * sizeof(T)));
+    HIP_OK(dev_malloc(&p, n * sizeof(T)));
     allocs_.push_back(p);
     device_bytes_ += (long long)(n * sizeof(T));
     return (T *)p;
@@ -110,6 +111,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     adj_ = Fields{s + 13 * n, s + 14 * n, s + 15 * n, s + 16 * n, s + 17 * n};
     media_ = dalloc<float>(6 * n);
     HIP_OK(hipMemset(media_, 0, 6 * n * sizeof(float)));
+    HIP_OK(hipDeviceSynchronize());  // the fill runs on the null stream and does not block the host; a caller's non-blocking stream would not wait for it
     md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n};
     acc_buf_ = dalloc<float>(5 * n);
     acc_ = ImgAcc{acc_buf_, acc_buf_ + n, acc_buf_ + 2 * n, acc_buf_ + 3 * n, acc_buf_ + 4 * n};
@@ -247,14 +249,14 @@ void Session::ensure_lanes(int n_lanes, bool with_frames) {
             HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
         }
         if (!L.state) {
-            HIP_OK(hipMalloc((void **)&L.state, 13 * n * sizeof(float)));
-            HIP_OK(hipMalloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
-            HIP_OK(hipMalloc((void **)&L.res, data_len_ * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.state, 13 * n * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.res, data_len_ * sizeof(float)));
             device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
         }
         if (with_frames && !L.frame) {
             const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
-            HIP_OK(hipMalloc((void **)&L.frame, fb));
+            HIP_OK(dev_malloc((void **)&L.frame, fb));
             device_bytes_ += (long long)fb;
         }
     }
@@ -268,32 +270,32 @@ void Session::ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots) 
     for (int k = 0; k < n_fwd; k++) {
         BLane &L = bl_[k];
         if (!L.state) {
-            HIP_OK(hipMalloc((void **)&L.state, 13 * n * sizeof(float)));
-            HIP_OK(hipMalloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
-            HIP_OK(hipMalloc((void **)&L.res, data_len_ * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.state, 13 * n * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.res, data_len_ * sizeof(float)));
             device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
         }
         if (with_frames && !L.frame) {
             const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
-            HIP_OK(hipMalloc((void **)&L.frame, fb));
+            HIP_OK(dev_malloc((void **)&L.frame, fb));
             device_bytes_ += (long long)fb;
         }
         if (k < n_bwd && !L.bwd) {
-            HIP_OK(hipMalloc((void **)&L.bwd, 18 * n * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&L.bwd, 18 * n * sizeof(float)));
             device_bytes_ += (long long)(18 * n * sizeof(float));
         }
     }
     if (n_shots > shots_cap_) {
         if (d_shots_) (void)hipFree(d_shots_);
         d_shots_ = nullptr;
-        HIP_OK(hipMalloc((void **)&d_shots_, (size_t)n_shots * sizeof(ShotDev)));
+        HIP_OK(dev_malloc((void **)&d_shots_, (size_t)n_shots * sizeof(ShotDev)));
         shots_cap_ = n_shots;
     }
     const size_t need = (size_t)n_shots * par_.nSteps;
     if (need > d_stf_len_) {
         if (d_stf_) (void)hipFree(d_stf_);
         d_stf_ = nullptr;
-        HIP_OK(hipMalloc((void **)&d_stf_, need * sizeof(float)));
+        HIP_OK(dev_malloc((void **)&d_stf_, need * sizeof(float)));
         d_stf_len_ = need;
     }
 }
@@ -328,7 +330,7 @@ void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) 
         }
     }
     if (nrec > 0 && !e.d_ett) {
-        HIP_OK(hipMalloc((void **)&e.d_ett, want));
+        HIP_OK(dev_malloc((void **)&e.d_ett, want));
         device_bytes_ += (long long)want;
     }
     e.bytes = want;
@@ -425,7 +427,7 @@ const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
         }
     }
     if (!e.d_ett) {
-        HIP_OK(hipMalloc((void **)&e.d_ett, want));
+        HIP_OK(dev_malloc((void **)&e.d_ett, want));
         device_bytes_ += (long long)want;
     }
     e.bytes = want;
@@ -514,7 +516,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     // ---- boundary-saving storage (Boundary.cu:29-41), allocated on first gradient call ----
     if (withAdj && !frame_) {
         const size_t fb = (size_t)nSteps * 5 * (size_t)g.frame_len * sizeof(float);
-        HIP_OK(hipMalloc((void **)&frame_, fb));
+        HIP_OK(dev_malloc((void **)&frame_, fb));
         device_bytes_ += (long long)fb;
     }
     if (withAdj) HIP_OK(hipMemsetAsync(acc_buf_, 0, 5 * n * sizeof(float), st));  // Model.cu:68-71
@@ -558,7 +560,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         if (need > stf_grad_len_) {
             if (stf_grad_) (void)hipFree(stf_grad_);
             stf_grad_ = nullptr;
-            HIP_OK(hipMalloc((void **)&stf_grad_, need * sizeof(float)));
+            HIP_OK(dev_malloc((void **)&stf_grad_, need * sizeof(float)));
             device_bytes_ += (long long)((need - stf_grad_len_) * sizeof(float));
             stf_grad_len_ = need;
         }
