@@ -251,21 +251,25 @@ Conditioner::Plans &Conditioner::plans_for(int nrec, hipStream_t st) {
     return it->second;
 }
 
-void Conditioner::ensure_source_buffers() {
+void Conditioner::ensure_source_buffers(hipStream_t st) {
     if (pad2_) return;
     const size_t npad = 2 * (size_t)nt_, nf = (size_t)nt_ + 1;
     if (dev_malloc((void **)&pad2_, npad * cap_ * sizeof(float)) != hipSuccess ||
         dev_malloc((void **)&spec2_, nf * cap_ * sizeof(hipfftComplex)) != hipSuccess ||
         dev_malloc((void **)&coef_, nf * sizeof(hipfftComplex)) != hipSuccess)
         throw std::runtime_error("conditioning: out of device memory (source update)");
-    if (hipMemset(coef_, 0, nf * sizeof(hipfftComplex)) != hipSuccess) throw std::runtime_error("conditioning: hipMemset failed");
+    // ON THE CALLER'S STREAM: a plain hipMemset runs on the null stream without blocking the host, the session's streams are
+    // non-blocking ones that do not wait for it, and it could land after k_matching_coef has written the coefficients -- zeroing
+    // the first shot's source update or (later still) only its adjoint step: misfit right, gradient short of one shot.  That is
+    // what a six-process fuzz sweep of round 3 caught once in about 15 000 draws (seed 11558: gradient 45 % off, 1.5e-6 when repeated).
+    if (hipMemsetAsync(coef_, 0, nf * sizeof(hipfftComplex), st) != hipSuccess) throw std::runtime_error("conditioning: hipMemsetAsync failed");
 }
 
 // source_update, utilities.cu:1170-1281
 void Conditioner::source_update(hipStream_t st, const float *obs, float *syn, int nrec, float dt) {
     if (nrec <= 0) return;
     if (nrec > cap_) throw std::invalid_argument("conditioning: more traces than the session was sized for");
-    ensure_source_buffers();
+    ensure_source_buffers(st);
     const int npad = 2 * nt_, nf = nt_ + 1;
     Plans &pl = plans_for(nrec, st);
     hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;
@@ -286,7 +290,7 @@ void Conditioner::source_update(hipStream_t st, const float *obs, float *syn, in
 void Conditioner::source_update_adj(hipStream_t st, float *res, int nrec, float dt) {
     if (nrec <= 0) return;
     if (nrec > cap_) throw std::invalid_argument("conditioning: more traces than the session was sized for");
-    ensure_source_buffers();
+    ensure_source_buffers(st);
     const int npad = 2 * nt_, nf = nt_ + 1;
     Plans &pl = plans_for(nrec, st);
     hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;

@@ -41,7 +41,7 @@ class Conditioner {
         void *fwd, *inv;  // hipfftHandle
     };
     Plans &plans_for(int nrec, hipStream_t st);
-    void ensure_source_buffers();
+    void ensure_source_buffers(hipStream_t st);
     int nt_, cap_;
     float *pad_ = nullptr, *norm_ = nullptr, *pad2_ = nullptr;
     void *spec_ = nullptr;  // hipfftComplex [cap][nt + 1]

@@ -206,6 +206,9 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         device_bytes_ += cond_->device_bytes();
     }
     HIP_OK(hipHostMalloc((void **)&h_io_, dlen * sizeof(float), hipHostMallocDefault));
+    // everything the constructor put on the null stream (fills, profile / receiver tables copied from pageable host memory) is
+    // complete before any stream of a later call -- the session's own non-blocking ones or a caller's -- can touch it
+    HIP_OK(hipDeviceSynchronize());
 }
 
 Session::~Session() {
