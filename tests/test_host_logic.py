@@ -448,3 +448,25 @@ def test_coarse_parameter_grid_is_interpolated(monkeypatch, tmp_path):
     fwi2 = M.FWI(c(3000.0), c(1700.0), c(2400.0), pb["Stf"], opt)
     fwi2(pb["Shot_ids"], ngpu=1)
     assert torch.allclose(fake.calls[1][2], torch.full((pb["nz_pad"], pb["nx_pad"]), 2400.0))
+
+
+def test_header_is_valid_c_and_cpp(tmp_path):
+    """include/sepfwi.h compiles as C99 and as C++17 (the reference's shim, Src/Torch_Fwi.cpp, is C++: INTEGRATION.md option A), warnings
+    as errors, and a C++ caller written as that document shows type-checks against it."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "t.c"
+    c.write_text('#include "sepfwi.h"\nint main(void) { return sepfwi_version() > 0 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(c)])
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include <stdexcept>\n#include <string>\n#include "sepfwi.h"\n'
+                   'float call(float *gL, float *gM, float *gD, float *gS, const float *L, const float *M, const float *D, const float *stf,\n'
+                   '           int gpu, int n, const int *ids, const std::string &para) {\n'
+                   '    float misfit = 0.0f;\n'
+                   '    if (sepfwi_cufd(&misfit, gL, gM, gD, gS, L, M, D, stf, 1, gpu, n, ids, para.c_str()) != 0)\n'
+                   '        throw std::runtime_error(sepfwi_last_error());\n'
+                   '    return misfit;\n}\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)])
