@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""How well-conditioned is a fuzz draw?  Runs tests/test_gpu_fuzz.py's draw(s) with the PRODUCT replaced by a second build of the oracle
+(gcc -O3 -march=native -ffp-contract=fast: the same algorithm with other round-off) against the regular oracle build, on the CPU.
+A draw on which the reference algorithm differs from ITSELF by 1e-3 is no 1e-3 parity target for anybody.
+    python scripts/fuzz_two_roundings.py 25550,167        (prints the test's diagnostics: rel-L2 per gradient, in / below a water layer)"""
+import os, sys, importlib.util, tempfile, pathlib
+os.environ["SEPFWI_FUZZ_SEEDS"] = sys.argv[1]
+os.environ["SEPFWI_FUZZ_DIAG"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'sep-2023_amd'), os.path.join(ROOT, 'tests')]
+import numpy as np, torch
+from oracle import oracle as O
+O.build()
+spec = importlib.util.spec_from_file_location("oracle_alt", os.path.join(ROOT, "oracle", "oracle.py"))
+OA = importlib.util.module_from_spec(spec); spec.loader.exec_module(OA)
+OA._LIB_PATH = "/tmp/liboracle_fast.so"
+import subprocess
+subprocess.check_call("gcc -O3 -march=native -ffp-contract=fast -fopenmp -fPIC -shared -o /tmp/liboracle_fast.so /root/repo/oracle/torchfwi_oracle.c "
+                      "/root/repo/oracle/numba_oracle.c -lm".replace("/root/repo", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), shell=True)
+class AltOps:
+    def __init__(self): self._o = OA.TorchFWIOracle()
+    _np = staticmethod(lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
+    def obscalc(self, L, M, D, S, ngpu, ids, pf): return self._o.obscalc(self._np(L), self._np(M), self._np(D), self._np(S), ngpu, self._np(ids), pf)
+    def backward(self, L, M, D, S, ngpu, ids, pf):
+        return [torch.from_numpy(np.ascontiguousarray(a)) for a in self._o.backward(self._np(L), self._np(M), self._np(D), self._np(S), ngpu, self._np(ids), pf)]
+import test_gpu_fuzz as T
+for seed in T._SEEDS:
+    try:
+        T.test_random_problem_matches_oracle(pathlib.Path(tempfile.mkdtemp()), O, AltOps(), seed)
+        print("seed", seed, "passed")
+    except AssertionError as e:
+        print("seed", seed, "ASSERT", str(e)[:200])
+    except BaseException as e:      # pytest.skip raises an exception of its own
+        print("seed", seed, type(e).__name__, str(e)[:120])
