@@ -242,3 +242,29 @@ def test_only_one_field_inverted_on_hip_tensors(tmp_path, hip_ops):
         g = jac(obj.x0).reshape(pb["init"]["vp"].shape)
         w = getattr(full, name).grad.cpu().numpy().astype(np.float64)
         assert np.abs(g - w).max() <= 1e-6 * np.abs(w).max(), name
+
+
+def test_whole_iteration_on_a_side_torch_stream(tmp_path, hip_ops):
+    """Module -> fused maps -> propagator -> chain rule with everything issued on a NON-default torch stream (the library then runs
+    on that caller's stream and does not order itself behind the default one): same loss and gradients as on the default stream,
+    bit for bit, also when the tensors were produced on the side stream just before."""
+    from sepfwi import modules as M
+    pb = P.make_problem(str(tmp_path), hetero=True, nSteps=150, nshots=3)
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])
+    res = []
+    for side in (None, torch.cuda.Stream()):
+        ctx = torch.cuda.stream(side) if side is not None else torch.cuda.stream(torch.cuda.default_stream())
+        hip_ops.release()
+        with ctx:
+            f = [torch.tensor(pb["init"][k], device="cuda").mul_(1.0).requires_grad_(True) for k in ("vp", "vs", "rho")]
+            fwi = M.FWI(f[0], f[1], f[2], pb["Stf"], pb["opt"])
+            loss = fwi(pb["Shot_ids"], ngpu=1)
+            loss.backward()
+            if side is not None:
+                side.synchronize()
+        torch.cuda.synchronize()
+        res.append([float(loss.detach())] + [p.grad.cpu() for p in fwi.parameters()])
+    assert res[0][0] == res[1][0] and res[0][0] > 0
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
