@@ -37,12 +37,9 @@ struct Grid {
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
     int amu_fly;  // 1: the 4-point harmonic mean of mu recomputed from mu in the stress-type kernels
     int nb, shot_fastest;  // batched launches: shots per grid and the order of (tile, shot) in the block index
-    int acc_nt;   // 1: the imaging accumulators are read / written with non-temporal accesses
 };
 
-// Five wavefields (or their adjoint twins), each n = (nzc+4)*pitch floats, ALWAYS one contiguous block of 5 n floats that
-// starts at vz.  Host-side descriptor: with option "pair" the kernels address the same block as
-// [(vz,vx) x n | (szz,sxx) x n | sxz] (csrc/device_common.hpp F5) and only `vz` (the base) and `vx - vz` (= n) are used.
+// Five wavefields (or their adjoint twins), each nzc*pitch floats.
 struct Fields {
     float *vz, *vx, *szz, *sxx, *sxz;
 };
@@ -73,8 +70,7 @@ struct PmlCoef {
 //   a   : sum_t -vz_a (dszz_dz+dsxz_dx) dt                   at the vz point
 //   b   : sum_t -vx_a (dsxz_dz+dsxx_dx) dt                   at the vx point
 // The constant-in-time factors (MEGA, mu-harmonic weights, -byc^2/2) and the 4-/2-point spray are
-// applied once per call by k_finalize_gradients.  One contiguous block of 5 n floats starting at lam; with option "pair" bit 2
-// addressed as [(lam,mu) x n | xz | (a,b) x n] (device_common.hpp Acc5).
+// applied once per call by k_finalize_gradients.
 struct ImgAcc {
     float *lam, *mu, *xz, *a, *b;
 };

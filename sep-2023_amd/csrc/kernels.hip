@@ -29,7 +29,6 @@
 
 #include <mutex>
 #include <string>
-#include <type_traits>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -106,53 +105,14 @@ __device__ __forceinline__ float ave_mu_at(const Grid &g, const Media &md, size_
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// The four derivatives of the velocity pair / of the three stresses that the stress-type / velocity-type updates need, from
-// pair taps (device_common.hpp F5): 9 and 7 + 7 loads per cell with the interleaved layout, 14 and 15 with the planar one.
-// ---------------------------------------------------------------------------------------------
-struct VDer {
-    float dvz_dz, dvx_dx, dvx_dz, dvz_dx, vz0, vx0, vxm1;
-};
-template <bool PF>
-__device__ __forceinline__ VDer v_derivs(const Grid &g, const F5<PF> &f, size_t i) {
-    const size_t P = g.pitch;
-    const f2 c0 = f.v(i), xm2 = f.v(i - 2), xm1 = f.v(i - 1), xp1 = f.v(i + 1), xp2 = f.v(i + 2);
-    const f2 zm2 = f.v(i - 2 * P), zm1 = f.v(i - P), zp1 = f.v(i + P), zp2 = f.v(i + 2 * P);
-    VDer d;
-    d.vz0 = c0.x;
-    d.vx0 = c0.y;
-    d.vxm1 = xm1.y;
-    d.dvz_dz = dminus(zm2.x, zm1.x, c0.x, zp1.x, g.rdz);
-    d.dvx_dx = dminus(xm2.y, xm1.y, c0.y, xp1.y, g.rdx);
-    d.dvx_dz = dplus(zm1.y, c0.y, zp1.y, zp2.y, g.rdz);
-    d.dvz_dx = dplus(xm1.x, c0.x, xp1.x, xp2.x, g.rdx);
-    return d;
-}
-struct SDer {
-    float dszz_dz, dsxz_dx, dsxz_dz, dsxx_dx;
-};
-template <bool PF>
-__device__ __forceinline__ SDer s_derivs(const Grid &g, const F5<PF> &f, size_t i) {
-    const size_t P = g.pitch;
-    const f2 c0 = f.s(i), xm1 = f.s(i - 1), xp1 = f.s(i + 1), xp2 = f.s(i + 2);
-    const f2 zm1 = f.s(i - P), zp1 = f.s(i + P), zp2 = f.s(i + 2 * P);
-    const float t0 = f.sxz(i);
-    SDer d;
-    d.dszz_dz = dplus(zm1.x, c0.x, zp1.x, zp2.x, g.rdz);
-    d.dsxz_dx = dminus(f.sxz(i - 2), f.sxz(i - 1), t0, f.sxz(i + 1), g.rdx);
-    d.dsxz_dz = dminus(f.sxz(i - 2 * P), f.sxz(i - P), t0, f.sxz(i + P), g.rdz);
-    d.dsxx_dx = dplus(xm1.y, c0.y, xp1.y, xp2.y, g.rdx);
-    return d;
-}
-
-// ---------------------------------------------------------------------------------------------
 // stress update
 // ---------------------------------------------------------------------------------------------
-template <bool FWD, bool SAVE, bool PF, bool PA, bool PC>
-__device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const F5<PF> &f, const PmlMem &m, const Media &md,
+template <bool FWD, bool SAVE>
+__device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
-                                            const F5<PA> &adj, const Acc5<PC> &acc, const LineRec &lr) {
-    const int z = c.z, x = c.x;
+                                            const Fields &adj, const ImgAcc &acc, const LineRec &lr) {
+    const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
 
@@ -162,31 +122,32 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             const int s = frame_slot(g, z, x);
             if (s >= 0) {
                 const int L = g.frame_len;
-                const f2 ss = f.s(i), vv = f.v(i);
-                frame_t[s] = ss.x;
-                frame_t[L + s] = f.sxz(i);
-                frame_t[2 * L + s] = ss.y;
-                frame_t[3 * L + s] = vv.x;
-                frame_t[4 * L + s] = vv.y;
+                frame_t[s] = f.szz[i];
+                frame_t[L + s] = f.sxz[i];
+                frame_t[2 * L + s] = f.sxx[i];
+                frame_t[3 * L + s] = f.vz[i];
+                frame_t[4 * L + s] = f.vx[i];
             }
         }
         if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_stress.cu:52
 
         // every unconditional load of the cell is issued here, before the first store: a store makes the compiler
         // keep all later (may-alias) loads behind it, i.e. one more dependent memory round trip per wave
-        const VDer d = v_derivs(g, f, i);
-        float dvz_dz = d.dvz_dz, dvx_dx = d.dvx_dx, dvx_dz = d.dvx_dz, dvz_dx = d.dvz_dx;
+        const float vz0 = f.vz[i], vx0 = f.vx[i], vxm1 = f.vx[i - 1];
+        float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], vz0, f.vz[i + P], g.rdz);
+        float dvx_dx = dminus(f.vx[i - 2], vxm1, vx0, f.vx[i + 1], g.rdx);
+        float dvx_dz = dplus(f.vx[i - P], vx0, f.vx[i + P], f.vx[i + 2 * P], g.rdz);
+        float dvz_dx = dplus(f.vz[i - 1], vz0, f.vz[i + 1], f.vz[i + 2], g.rdx);
         const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
-        const f2 s0 = f.s(i);
-        const float sxz0 = f.sxz(i);
+        const float szz0 = f.szz[i], sxx0 = f.sxx[i], sxz0 = f.sxz[i];
         if (lr.n && z == lr.z) {
             // line receivers: seismogram column `it` = velocities at the START of step `it`, which this kernel
             // only reads (recording_vx / _vz / _exx, utilities.cu:593-602,645-677)
             const int r = x - lr.x0;
             if (r >= 0 && r < lr.n) {
-                if (lr.d_vx) lr.d_vx[r] = d.vx0;
-                if (lr.d_vz) lr.d_vz[r] = d.vz0;
-                if (lr.d_ett) lr.d_ett[r] = d.vx0 - d.vxm1;
+                if (lr.d_vx) lr.d_vx[r] = vx0;
+                if (lr.d_vz) lr.d_vz[r] = vz0;
+                if (lr.d_ett) lr.d_ett[r] = vx0 - vxm1;
             }
         }
 
@@ -207,14 +168,15 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             dvz_dx = dvz_dx * pc.rK_xh[x] + q;
         }
         const float l2m = lam + 2.0f * mu;
-        float szz = s0.x + (l2m * dvz_dz + lam * dvx_dx) * g.dt;
-        float sxx = s0.y + (lam * dvz_dz + l2m * dvx_dx) * g.dt;
+        float szz = szz0 + (l2m * dvz_dz + lam * dvx_dx) * g.dt;
+        float sxx = sxx0 + (lam * dvz_dz + l2m * dvx_dx) * g.dt;
         if (z == z_src && x == x_src) {  // add_source, utilities.cu:531-538
             szz += src_amp;
             sxx += src_amp;
         }
-        f.set_s(i, szz, sxx);
-        f.set_sxz(i, sxz0 + amu * (dvx_dz + dvz_dx) * g.dt);
+        f.szz[i] = szz;
+        f.sxx[i] = sxx;
+        f.sxz[i] = sxz0 + amu * (dvx_dz + dvz_dx) * g.dt;
     } else {
         // ---- reverse-time reconstruction + lambda/mu imaging ----
         const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
@@ -222,23 +184,23 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
         if (!interior && s < 0) return;
         float szz = 0.f, sxx = 0.f, sxz = 0.f;
         if (interior) {
-            const f2 s0 = f.s(i);
-            szz = s0.x;
-            sxx = s0.y;
-            sxz = f.sxz(i);
+            szz = f.szz[i];
+            sxx = f.sxx[i];
+            sxz = f.sxz[i];
             if (z == z_src && x == x_src) {  // add_source(isFor=false) comes first (libCUFD.cu:566-569)
                 szz -= src_amp;
                 sxx -= src_amp;
             }
-            const VDer d = v_derivs(g, f, i);
-            const float dvz_dz = d.dvz_dz, dvx_dx = d.dvx_dx, dvx_dz = d.dvx_dz, dvz_dx = d.dvz_dx;
+            const float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
+            const float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
+            const float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
+            const float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
             const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
             const bool img = g.dt_img != 0.0f;  // launch-uniform: option img_every images every k-th step only
             float za = 0.f, xa = 0.f, sa = 0.f, g_lam = 0.f, g_mu = 0.f, g_xz = 0.f;
             if (img) {
-                const f2 as = adj.s(i), lm = acc.lm(i);
-                za = as.x; xa = as.y; sa = adj.sxz(i);
-                g_lam = lm.x; g_mu = lm.y; g_xz = acc.xz(i);
+                za = adj.szz[i]; xa = adj.sxx[i]; sa = adj.sxz[i];
+                g_lam = acc.lam[i]; g_mu = acc.mu[i]; g_xz = acc.xz[i];
             }
             const float l2m = lam + 2.0f * mu;
             szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
@@ -246,8 +208,9 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             sxz -= amu * (dvx_dz + dvz_dx) * g.dt;
             if (img) {
                 // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
-                acc.set_lm(i, g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img, g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img);
-                acc.set_xz(i, g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img);
+                acc.lam[i] = g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img;
+                acc.mu[i] = g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img;
+                acc.xz[i] = g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img;
             }
         }
         if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
@@ -256,8 +219,9 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             sxz = frame_t[L + s];
             sxx = frame_t[2 * L + s];
         }
-        f.set_s(i, szz, sxx);
-        f.set_sxz(i, sxz);
+        f.szz[i] = szz;
+        f.sxx[i] = sxx;
+        f.sxz[i] = sxz;
     }
 }
 
@@ -280,20 +244,22 @@ __device__ __forceinline__ void buoyancies(const Grid &g, const Media &md, size_
     }
 }
 
-template <bool FWD, bool PF, bool PA, bool PC>
-__device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const F5<PF> &f, const PmlMem &m, const Media &md,
+template <bool FWD>
+__device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
-                                              float src_rxz, float *__restrict__ stf_grad_it, const F5<PA> &adj,
-                                              const Acc5<PC> &acc) {
-    const int z = c.z, x = c.x;
+                                              float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
+                                              const ImgAcc &acc) {
+    const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
 
     if constexpr (FWD) {
         if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_velocity.cu:47
-        const SDer d = s_derivs(g, f, i);
-        float dszz_dz = d.dszz_dz, dsxz_dx = d.dsxz_dx, dsxz_dz = d.dsxz_dz, dsxx_dx = d.dsxx_dx;
-        const f2 v0 = f.v(i);  // all loads before the first store
+        float dszz_dz = dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
+        float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
+        float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
+        float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+        const float vz0 = f.vz[i], vx0 = f.vx[i];  // all loads before the first store
         float ba, bb;
         buoyancies(g, md, i, ba, bb);
         if (in_pml_z(g, z)) {
@@ -312,34 +278,33 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             m.dsxx_dx[i] = q;
             dsxx_dx = dsxx_dx * pc.rK_xh[x] + q;
         }
-        f.set_v(i, v0.x + (dszz_dz + dsxz_dx) * ba * g.dt, v0.y + (dsxz_dz + dsxx_dx) * bb * g.dt);
+        f.vz[i] = vz0 + (dszz_dz + dsxz_dx) * ba * g.dt;
+        f.vx[i] = vx0 + (dsxz_dz + dsxx_dx) * bb * g.dt;
     } else {
         // source_grad uses the adjoint stresses as they stand at the start of the step (libCUFD.cu:547)
-        if (z == z_src && x == x_src) {
-            const f2 as = adj.s(i);
-            *stf_grad_it = -(as.x + src_rxz * as.y) * g.dt;
-        }
+        if (z == z_src && x == x_src) *stf_grad_it = -(adj.szz[i] + src_rxz * adj.sxx[i]) * g.dt;
         const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
         const int s = frame_slot(g, z, x);
         if (!interior && s < 0) return;
         float vz = 0.f, vx = 0.f;
         if (interior) {
-            const SDer d = s_derivs(g, f, i);
-            const float dszz_dz = d.dszz_dz, dsxz_dx = d.dsxz_dx, dsxz_dz = d.dsxz_dz, dsxx_dx = d.dsxx_dx;
+            const float dszz_dz = dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
+            const float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
+            const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
+            const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
             const bool img = g.dt_img != 0.0f;  // launch-uniform
             float g_a = 0.f, g_b = 0.f, avz = 0.f, avx = 0.f;
             if (img) {
-                const f2 ab = acc.ab(i), av = adj.v(i);
-                g_a = ab.x; g_b = ab.y; avz = av.x; avx = av.y;
+                g_a = acc.a[i]; g_b = acc.b[i]; avz = adj.vz[i]; avx = adj.vx[i];
             }
             float ba, bb;
             buoyancies(g, md, i, ba, bb);
-            const f2 v0 = f.v(i);
-            vz = v0.x - (dszz_dz + dsxz_dx) * ba * g.dt;
-            vx = v0.y - (dsxz_dz + dsxx_dx) * bb * g.dt;
+            vz = f.vz[i] - (dszz_dz + dsxz_dx) * ba * g.dt;
+            vx = f.vx[i] - (dsxz_dz + dsxx_dx) * bb * g.dt;
             if (img) {
                 // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
-                acc.set_ab(i, g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img, g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img);
+                acc.a[i] = g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img;
+                acc.b[i] = g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img;
             }
         }
         if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
@@ -347,7 +312,8 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             vz = frame_t[3 * L + s];
             vx = frame_t[4 * L + s];
         }
-        f.set_v(i, vz, vx);
+        f.vz[i] = vz;
+        f.vx[i] = vx;
     }
 }
 
@@ -377,31 +343,30 @@ __device__ __forceinline__ void load_rK(const Grid &g, const PmlCoef &pc, int z,
 
 struct VelAdjIn {
     bool on;
-    f2 s_xm1, s_0, s_xp1, s_xp2, s_zm1, s_zp1, s_zp2;  // (szz, sxx): both members are tapped at the same seven offsets
+    float szz_xm1, szz_0, szz_xp1, szz_xp2, szz_zm1, szz_zp1, szz_zp2;
+    float sxx_xm1, sxx_0, sxx_xp1, sxx_xp2, sxx_zm1, sxx_zp1, sxx_zp2;
     float sxz_zm2, sxz_zm1, sxz_0, sxz_zp1, sxz_xm2, sxz_xm1, sxz_xp1;
     float vx, vz, lam, mu, amu, rKx, rKxh, rKz, rKzh;
 };
-template <bool PA>
-__device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell &c, const F5<PA> &f, const Media &md,
+__device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell &c, const Fields &f, const Media &md,
                                                       const PmlCoef &pc) {
     VelAdjIn q;
-    const int z = c.z, x = c.x;
-    const size_t P = g.pitch;
+    const int z = c.z, x = c.x, P = g.pitch;
     q.on = !(z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3);
     if (!q.on) return q;
     const size_t i = c.i;
-    q.s_xm1 = f.s(i - 1); q.s_0 = f.s(i); q.s_xp1 = f.s(i + 1); q.s_xp2 = f.s(i + 2);
-    q.s_zm1 = f.s(i - P); q.s_zp1 = f.s(i + P); q.s_zp2 = f.s(i + 2 * P);
-    q.sxz_zm2 = f.sxz(i - 2 * P); q.sxz_zm1 = f.sxz(i - P); q.sxz_0 = f.sxz(i); q.sxz_zp1 = f.sxz(i + P);
-    q.sxz_xm2 = f.sxz(i - 2); q.sxz_xm1 = f.sxz(i - 1); q.sxz_xp1 = f.sxz(i + 1);
-    const f2 v0 = f.v(i);
-    q.vz = v0.x; q.vx = v0.y;
+    q.szz_xm1 = f.szz[i - 1]; q.szz_0 = f.szz[i]; q.szz_xp1 = f.szz[i + 1]; q.szz_xp2 = f.szz[i + 2];
+    q.szz_zm1 = f.szz[i - P]; q.szz_zp1 = f.szz[i + P]; q.szz_zp2 = f.szz[i + 2 * P];
+    q.sxx_xm1 = f.sxx[i - 1]; q.sxx_0 = f.sxx[i]; q.sxx_xp1 = f.sxx[i + 1]; q.sxx_xp2 = f.sxx[i + 2];
+    q.sxx_zm1 = f.sxx[i - P]; q.sxx_zp1 = f.sxx[i + P]; q.sxx_zp2 = f.sxx[i + 2 * P];
+    q.sxz_zm2 = f.sxz[i - 2 * P]; q.sxz_zm1 = f.sxz[i - P]; q.sxz_0 = f.sxz[i]; q.sxz_zp1 = f.sxz[i + P];
+    q.sxz_xm2 = f.sxz[i - 2]; q.sxz_xm1 = f.sxz[i - 1]; q.sxz_xp1 = f.sxz[i + 1];
+    q.vx = f.vx[i]; q.vz = f.vz[i];
     q.lam = md.lam[i]; q.mu = md.mu[i]; q.amu = ave_mu_at(g, md, i, q.mu);
     load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
-template <bool PA>
-__device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const F5<PA> &f,
+__device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
                                                    const PmlMem &m, const Media &md, const PmlCoef &pc, const LineRec &lr) {
     if (!q.on) return;
     const int z = c.z, x = c.x, P = g.pitch;
@@ -412,13 +377,13 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
     const float l2m = lam + 2.0f * q.mu;
 
     // vx
-    const float dszz_dx = -dplus(q.s_xm1.x, q.s_0.x, q.s_xp1.x, q.s_xp2.x, g.rdx);
-    const float dsxx_dx = -dplus(q.s_xm1.y, q.s_0.y, q.s_xp1.y, q.s_xp2.y, g.rdx);
+    const float dszz_dx = -dplus(q.szz_xm1, q.szz_0, q.szz_xp1, q.szz_xp2, g.rdx);
+    const float dsxx_dx = -dplus(q.sxx_xm1, q.sxx_0, q.sxx_xp1, q.sxx_xp2, g.rdx);
     const float dsxz_dz = -dminus(q.sxz_zm2, q.sxz_zm1, q.sxz_0, q.sxz_zp1, g.rdz);
     float upd = lam * dszz_dx * q.rKx * g.dt + l2m * dsxx_dx * q.rKx * g.dt + amu * q.rKzh * dsxz_dz * g.dt;
     // vz
-    const float dszz_dz = -dplus(q.s_zm1.x, q.s_0.x, q.s_zp1.x, q.s_zp2.x, g.rdz);
-    const float dsxx_dz = -dplus(q.s_zm1.y, q.s_0.y, q.s_zp1.y, q.s_zp2.y, g.rdz);
+    const float dszz_dz = -dplus(q.szz_zm1, q.szz_0, q.szz_zp1, q.szz_zp2, g.rdz);
+    const float dsxx_dz = -dplus(q.sxx_zm1, q.sxx_0, q.sxx_zp1, q.sxx_zp2, g.rdz);
     const float dsxz_dx = -dminus(q.sxz_xm2, q.sxz_xm1, q.sxz_0, q.sxz_xp1, g.rdx);
     float upz = l2m * dszz_dz * q.rKz * g.dt + lam * dsxx_dz * q.rKz * g.dt + amu * q.rKxh * dsxz_dx * g.dt;
     if (px) {
@@ -431,15 +396,18 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
     }
     const float vx = q.vx + upd;
     const float vz = q.vz + upz;
-    // res_injection_exx (utilities.cu:605-615) for line receivers, applied by the thread that owns the cell:
-    // vx_adj(z,x) += r[x]; vx_adj(z,x) -= r[x+1]   (after this kernel's update, libCUFD.cu:585-610)
-    float vs = vx;
-    if (lr.n && z == lr.z) {
-        const int r = x - lr.x0;
-        if (r >= 0 && r < lr.n) vs += lr.res[r];
-        if (r + 1 >= 0 && r + 1 < lr.n) vs -= lr.res[r + 1];
+    {
+        // res_injection_exx (utilities.cu:605-615) for line receivers, applied by the thread that owns the cell:
+        // vx_adj(z,x) += r[x]; vx_adj(z,x) -= r[x+1]   (after this kernel's update, libCUFD.cu:585-610)
+        float vs = vx;
+        if (lr.n && z == lr.z) {
+            const int r = x - lr.x0;
+            if (r >= 0 && r < lr.n) vs += lr.res[r];
+            if (r + 1 >= 0 && r + 1 < lr.n) vs -= lr.res[r + 1];
+        }
+        f.vx[i] = vs;
     }
-    f.set_v(i, vz, vs);
+    f.vz[i] = vz;
     if (px || pz) {  // the buoyancies are only needed inside the layers: keep their loads out of the interior
         const float bb = md.byc_b[i], ba = md.byc_a[i];
         if (px) {
@@ -452,8 +420,7 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
         }
     }
 }
-template <bool PA>
-__device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const F5<PA> &f, const PmlMem &m,
+__device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
                                                   const Media &md, const PmlCoef &pc, const LineRec &lr) {
     const VelAdjIn q = velocity_adj_load(g, c, f, md, pc);
     velocity_adj_apply(q, g, c, f, m, md, pc, lr);
@@ -467,28 +434,27 @@ __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, 
 // ---------------------------------------------------------------------------------------------
 struct StressAdjIn {
     bool on;
-    f2 v_xm2, v_xm1, v_0, v_xp1, v_xp2, v_zm2, v_zm1, v_zp1, v_zp2;  // (vz, vx); vz taps xm1..xp2, zm2..zp1, vx taps xm2..xp1, zm1..zp2
+    float vz_xm1, vz_0, vz_xp1, vz_xp2, vz_zm2, vz_zm1, vz_zp1;
+    float vx_zm1, vx_0, vx_zp1, vx_zp2, vx_xm2, vx_xm1, vx_xp1;
     float sxz, sxx, szz, ba, bb, rKx, rKxh, rKz, rKzh;
 };
-template <bool PA>
-__device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell &c, const F5<PA> &f, const Media &md,
+__device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell &c, const Fields &f, const Media &md,
                                                        const PmlCoef &pc) {
     StressAdjIn q;
-    const int z = c.z, x = c.x;
-    const size_t P = g.pitch;
+    const int z = c.z, x = c.x, P = g.pitch;
     q.on = !(z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3);
     if (!q.on) return q;
     const size_t i = c.i;
-    q.v_xm2 = f.v(i - 2); q.v_xm1 = f.v(i - 1); q.v_0 = f.v(i); q.v_xp1 = f.v(i + 1); q.v_xp2 = f.v(i + 2);
-    q.v_zm2 = f.v(i - 2 * P); q.v_zm1 = f.v(i - P); q.v_zp1 = f.v(i + P); q.v_zp2 = f.v(i + 2 * P);
-    const f2 s0 = f.s(i);
-    q.sxz = f.sxz(i); q.sxx = s0.y; q.szz = s0.x;
+    q.vz_xm1 = f.vz[i - 1]; q.vz_0 = f.vz[i]; q.vz_xp1 = f.vz[i + 1]; q.vz_xp2 = f.vz[i + 2];
+    q.vz_zm2 = f.vz[i - 2 * P]; q.vz_zm1 = f.vz[i - P]; q.vz_zp1 = f.vz[i + P];
+    q.vx_zm1 = f.vx[i - P]; q.vx_0 = f.vx[i]; q.vx_zp1 = f.vx[i + P]; q.vx_zp2 = f.vx[i + 2 * P];
+    q.vx_xm2 = f.vx[i - 2]; q.vx_xm1 = f.vx[i - 1]; q.vx_xp1 = f.vx[i + 1];
+    q.sxz = f.sxz[i]; q.sxx = f.sxx[i]; q.szz = f.szz[i];
     buoyancies(g, md, i, q.ba, q.bb);
     load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
-template <bool PA>
-__device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const F5<PA> &f,
+__device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
                                                  const PmlMem &m, const Media &md, const PmlCoef &pc) {
     if (!q.on) return;
     const int z = c.z, x = c.x, P = g.pitch;
@@ -500,12 +466,12 @@ __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Gri
     const float ba = q.ba, bb = q.bb;
 
     // sxz
-    const float dvz_dx = -dplus(q.v_xm1.x, q.v_0.x, q.v_xp1.x, q.v_xp2.x, g.rdx);
-    const float dvx_dz = -dplus(q.v_zm1.y, q.v_0.y, q.v_zp1.y, q.v_zp2.y, g.rdz);
+    const float dvz_dx = -dplus(q.vz_xm1, q.vz_0, q.vz_xp1, q.vz_xp2, g.rdx);
+    const float dvx_dz = -dplus(q.vx_zm1, q.vx_0, q.vx_zp1, q.vx_zp2, g.rdz);
     float us = dvz_dx * q.rKx * ba * g.dt + dvx_dz * q.rKz * bb * g.dt;
     // sxx, szz
-    const float dvx_dx = -dminus(q.v_xm2.y, q.v_xm1.y, q.v_0.y, q.v_xp1.y, g.rdx);
-    const float dvz_dz = -dminus(q.v_zm2.x, q.v_zm1.x, q.v_0.x, q.v_zp1.x, g.rdz);
+    const float dvx_dx = -dminus(q.vx_xm2, q.vx_xm1, q.vx_0, q.vx_xp1, g.rdx);
+    const float dvz_dz = -dminus(q.vz_zm2, q.vz_zm1, q.vz_0, q.vz_zp1, g.rdz);
     float ux = bb * dvx_dx * q.rKxh * g.dt;
     float uz = ba * dvz_dz * q.rKzh * g.dt;
     if (px) {
@@ -519,8 +485,9 @@ __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Gri
     const float sxz = q.sxz + us;
     const float sxx = q.sxx + ux;
     const float szz = q.szz + uz;
-    f.set_sxz(i, sxz);
-    f.set_s(i, szz, sxx);
+    f.sxz[i] = sxz;
+    f.sxx[i] = sxx;
+    f.szz[i] = szz;
     if (wx || wz) {  // lambda, mu, ave_mu only feed the memory variables, which only exist near the layers
         const float amu = md.ave_mu[i];
         const float lam = md.lam[i], mu = md.mu[i];
@@ -535,8 +502,7 @@ __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Gri
         }
     }
 }
-template <bool PA>
-__device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const F5<PA> &f, const PmlMem &m,
+__device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
                                                 const Media &md, const PmlCoef &pc) {
     const StressAdjIn q = stress_adj_load(g, c, f, md, pc);
     stress_adj_apply(q, g, c, f, m, md, pc);
@@ -545,23 +511,21 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
 // ---------------------------------------------------------------------------------------------
 // kernels: one body each (the reference's launch structure) ...
 // ---------------------------------------------------------------------------------------------
-template <bool FWD, bool SAVE, bool PF, bool PA, bool PC>
-__global__ __launch_bounds__(MAXT) void k_stress(Grid g, F5<PF> f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
-                                                 int z_src, int x_src, float src_amp, F5<PA> adj, Acc5<PC> acc, LineRec lr) {
+template <bool FWD, bool SAVE>
+__global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
+                                                 int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc, LineRec lr) {
     stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr);
 }
-template <bool FWD, bool PF, bool PA, bool PC>
-__global__ __launch_bounds__(MAXT) void k_velocity(Grid g, F5<PF> f, PmlMem m, Media md, PmlCoef pc,
+template <bool FWD>
+__global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
                                                    const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
-                                                   float *__restrict__ stf_grad_it, F5<PA> adj, Acc5<PC> acc) {
+                                                   float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
     velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
 }
-template <bool PA>
-__global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, F5<PA> f, PmlMem m, Media md, PmlCoef pc) {
+__global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     velocity_adj_body(g, my_cell(g), f, m, md, pc, LineRec{});
 }
-template <bool PA>
-__global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, F5<PA> f, PmlMem m, Media md, PmlCoef pc) {
+__global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     stress_adj_body(g, my_cell(g), f, m, md, pc);
 }
 
@@ -583,30 +547,31 @@ __global__ __launch_bounds__(MAXT) void k_stress_adj(Grid g, F5<PA> f, PmlMem m,
 // Arrays arrive as bundles (base pointer + stride) to keep the kernel's SGPR count at or below 80, the limit for
 // 8 waves per SIMD (MI355X_MICROARCH.md "Residency"): 37 separate pointers cost 74 SGPRs on their own.
 struct BwdArgs {
-    float *fields;       // the five wavefields, 5 n floats (layout: device_common.hpp F5)
+    float *fields;       // vz, vx, szz, sxx, sxz          (stride n)
     float *mem;          // 8 C-PML memory variables       (stride n)
-    float *adj;          // the five adjoint wavefields, 5 n floats
+    float *adj;          // adjoint vz, vx, szz, sxx, sxz  (stride n)
     const float *media;  // lam, mu, ave_mu, byc_a, byc_b  (stride n)
-    float *acc;          // the five imaging accumulators, 5 n floats (layout: Acc5)
+    float *acc;          // lam, mu, xz, a, b              (stride n)
     const float *cz;     // z profiles a, b, 1/K, a_half, b_half, 1/K_half (stride nzc), then the six x profiles (stride nx)
     size_t n;
 };
+__device__ __forceinline__ Fields fields_of(float *b, size_t n) { return Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
 __device__ __forceinline__ PmlMem mem_of(float *b, size_t n) {
     return PmlMem{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n};
 }
 __device__ __forceinline__ Media media_of(const float *b, size_t n) { return Media{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n}; }
+__device__ __forceinline__ ImgAcc acc_of(float *b, size_t n) { return ImgAcc{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
 __device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int nzc, int nx) {
     return PmlCoef{cz, cz + nzc, cz + 2 * nzc, cz + 3 * nzc, cz + 4 * nzc, cz + 5 * nzc,
                    cx, cx + nx,  cx + 2 * nx,  cx + 3 * nx,  cx + 4 * nx,  cx + 5 * nx};
 }
 
-template <bool EARLY, bool PF, bool PA, bool PC>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *__restrict__ frame_t) {
-    const F5<PF> f{b.fields, b.n};
-    const F5<PA> adj{b.adj, b.n};
+    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
     const PmlMem m = mem_of(b.mem, b.n);
     const Media md = media_of(b.media, b.n);
-    const Acc5<PC> acc{b.acc, b.n, g.acc_nt};
+    const ImgAcc acc = acc_of(b.acc, b.n);
     const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
     if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
@@ -618,24 +583,20 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
-template <bool EARLY, bool PF, bool PA, bool PC>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__restrict__ frame_t, int zx_src /* z<<16 | x */,
                                                 float src_amp, float src_rxz, float *__restrict__ stf_grad_it,
                                                 int lr_zx /* z<<16 | x0 */, int lr_n, const float *__restrict__ lr_res) {
     const int z_src = zx_src >> 16, x_src = zx_src & 0xffff;
     const LineRec lr{lr_zx >> 16, lr_zx & 0xffff, lr_n, nullptr, nullptr, nullptr, lr_res};
-    const F5<PF> f{b.fields, b.n};
-    const F5<PA> adj{b.adj, b.n};
+    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
     const PmlMem m = mem_of(b.mem, b.n);
     const Media md = media_of(b.media, b.n);
-    const Acc5<PC> acc{b.acc, b.n, g.acc_nt};
+    const ImgAcc acc = acc_of(b.acc, b.n);
     const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
     // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
-    if (c.z == z_src && c.x == x_src) {
-        const f2 as = adj.s(c.i);
-        *stf_grad_it = -(as.x + src_rxz * as.y) * g.dt;
-    }
+    if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
     if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
         stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
@@ -652,14 +613,14 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
 // 24 launches per shot and time step; the stream form 4; this one 4 / batch), and on the headline grid the three
 // concurrent forward passes become one launch whose blocks pack without stream scheduling.  Same bodies as above.
 // ---------------------------------------------------------------------------------------------
-template <bool SAVE, bool PF>
+template <bool SAVE>
 __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                            const float *__restrict__ cz, size_t n, size_t data_len, int it,
                                                            float src_scale) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const F5<PF> f{s.fields, n};
+    const Fields f = fields_of(s.fields, n);
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
@@ -676,31 +637,29 @@ __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev
         lr.d_vz = (s.comps & 4) ? s.syn + 2 * data_len + c0 : nullptr;
         lr.d_ett = (s.comps & 8) ? s.syn + 3 * data_len + c0 : nullptr;
     }
-    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, F5<false>{}, Acc5<false>{}, lr);
+    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, ImgAcc{}, lr);
 }
-template <bool PF>
 __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                              const float *__restrict__ cz, size_t n) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const F5<PF> f{s.fields, n};
+    const Fields f = fields_of(s.fields, n);
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
-    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, F5<false>{}, Acc5<false>{});
+    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, ImgAcc{});
 }
-template <bool EARLY, bool PF, bool PA, bool PC>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                       const float *__restrict__ cz, size_t n, int it) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const F5<PF> f{s.fields, n};
-    const F5<PA> adj{s.adj, n};
+    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(media, n);
-    const Acc5<PC> acc{s.acc, n, g.acc_nt};
+    const ImgAcc acc = acc_of(s.acc, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
     const float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
     if constexpr (EARLY) {
@@ -712,25 +671,21 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__r
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
-template <bool EARLY, bool PF, bool PA, bool PC>
+template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                       const float *__restrict__ cz, size_t n, int it, float src_scale) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const F5<PF> f{s.fields, n};
-    const F5<PA> adj{s.adj, n};
+    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(media, n);
-    const Acc5<PC> acc{s.acc, n, g.acc_nt};
+    const ImgAcc acc = acc_of(s.acc, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
     float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
     const float amp = __fmul_rn(__fmul_rn(src_scale, s.stf[it]), g.dt);
     const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
-    if (c.z == s.z_src && c.x == s.x_src) {  // source_grad
-        const f2 as = adj.s(c.i);
-        s.stf_grad[it] = -(as.x + s.src_rxz * as.y) * g.dt;
-    }
+    if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
     if constexpr (EARLY) {
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
         stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
@@ -746,44 +701,38 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
 // horizontal fibre); they are transposed to the reference's [rec][it] files only on export.
 // comps bit mask: 1 pressure, 2 vx, 4 vz, 8 ett.
 // ---------------------------------------------------------------------------------------------
-template <bool PF>
-__global__ void k_record(Grid g, F5<PF> f, int nrec, const int *__restrict__ rec_idx /* z*pitch+x */,
+__global__ void k_record(Grid g, Fields f, int nrec, const int *__restrict__ rec_idx /* z*pitch+x */,
                          float *__restrict__ d_pr, float *__restrict__ d_vx, float *__restrict__ d_vz,
                          float *__restrict__ d_ett, int comps, int fiber, const float *__restrict__ sens) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const int i = rec_idx[r];
-    if (comps & 1) {
-        const f2 s0 = f.s(i);
-        d_pr[r] = s0.x + s0.y;
-    }
-    const f2 v0 = f.v(i);
-    const float vx = v0.y;
+    if (comps & 1) d_pr[r] = f.szz[i] + f.sxx[i];
+    const float vx = f.vx[i];
     if (comps & 2) d_vx[r] = vx;
-    const float vz = v0.x;
+    const float vz = f.vz[i];
     if (comps & 4) d_vz[r] = vz;
     if (!(comps & 8)) return;
     if (sens) {
         // directional channel: ett = s0 exx + s3 ezz + s1 exz (MOD/elasticSolver.py:266-276), strains as one-cell differences in
         // units of "strain x dx" like recording_exx (the z-differences carry dx/dz)
         const float k = g.dx * g.rdz;
-        const float exx = vx - f.v(i - 1).y;
-        const float ezz = (vz - f.v(i - g.pitch).x) * k;
-        const float exz = 0.5f * ((f.v(i + g.pitch).y - vx) * k + (f.v(i + 1).x - vz));
+        const float exx = vx - f.vx[i - 1];
+        const float ezz = (vz - f.vz[i - g.pitch]) * k;
+        const float exz = 0.5f * ((f.vx[i + g.pitch] - vx) * k + (f.vz[i + 1] - vz));
         d_ett[r] = sens[3 * r] * exx + sens[3 * r + 1] * ezz + sens[3 * r + 2] * exz;
         return;
     }
     // axial strain over one cell, not divided by the spacing (utilities.cu:600-601): exx for a horizontal fibre,
     // ezz (recording_ezz, utilities.cu:620-629) for a vertical one
-    d_ett[r] = fiber ? vz - f.v(i - g.pitch).x : vx - f.v(i - 1).y;
+    d_ett[r] = fiber ? vz - f.vz[i - g.pitch] : vx - f.vx[i - 1];
 }
 
 // res_injection_exx: vx_adj(z,x) += r ; vx_adj(z,x-1) -= r.  Adjacent channels share cells, so the
 // two statements are applied through float atomics (the reference's plain +=/-= is racy there,
 // utilities.cu:613-614).  Atomic order only permutes a few adds per cell.  With `sens`: the transpose of the
 // directional channel above.
-template <bool PA>
-__global__ void k_inject(F5<PA> adj, int nrec, const int *__restrict__ rec_idx, const float *__restrict__ res_t,
+__global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, const float *__restrict__ res_t,
                          int down /* 0: horizontal fibre, else the pitch: vertical fibre (res_injection_ezz, utilities.cu:632-641) */,
                          const float *__restrict__ sens, int pitch, float dx_dz) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -792,20 +741,20 @@ __global__ void k_inject(F5<PA> adj, int nrec, const int *__restrict__ rec_idx, 
     const float v = res_t[r];
     if (sens) {
         const float a = sens[3 * r] * v, b = sens[3 * r + 1] * dx_dz * v, c = 0.5f * sens[3 * r + 2] * v;
-        atomicAdd(adj.p_vx(i), a);
-        atomicAdd(adj.p_vx(i - 1), -a);
-        atomicAdd(adj.p_vz(i), b);
-        atomicAdd(adj.p_vz(i - pitch), -b);
-        atomicAdd(adj.p_vx(i + pitch), c * dx_dz);
-        atomicAdd(adj.p_vx(i), -(c * dx_dz));
-        atomicAdd(adj.p_vz(i + 1), c);
-        atomicAdd(adj.p_vz(i), -c);
+        atomicAdd(&adj.vx[i], a);
+        atomicAdd(&adj.vx[i - 1], -a);
+        atomicAdd(&adj.vz[i], b);
+        atomicAdd(&adj.vz[i - pitch], -b);
+        atomicAdd(&adj.vx[i + pitch], c * dx_dz);
+        atomicAdd(&adj.vx[i], -(c * dx_dz));
+        atomicAdd(&adj.vz[i + 1], c);
+        atomicAdd(&adj.vz[i], -c);
     } else if (down) {
-        atomicAdd(adj.p_vz(i), v);
-        atomicAdd(adj.p_vz(i - down), -v);
+        atomicAdd(&adj.vz[i], v);
+        atomicAdd(&adj.vz[i - down], -v);
     } else {
-        atomicAdd(adj.p_vx(i), v);
-        atomicAdd(adj.p_vx(i - 1), -v);
+        atomicAdd(&adj.vx[i], v);
+        atomicAdd(&adj.vx[i - 1], -v);
     }
 }
 
@@ -904,19 +853,17 @@ __global__ void k_model_prep(Grid g, const float *__restrict__ Lam_in, const flo
 //   el_velocity.cu:101-110: gDen = A(z,x)+B(z,x)+A(z-1,x)+B(z,x-1), A = acc.a*(-byc_a^2/2), ...
 // including the reference's edge tests (the x+1 spray is unconditional).
 // ---------------------------------------------------------------------------------------------
-template <bool PC>
-__device__ __forceinline__ float xz_weight(const Grid &g, const Media &md, const Acc5<PC> &acc, int pz, int px) {
+__device__ __forceinline__ float xz_weight(const Grid &g, const Media &md, const ImgAcc &acc, int pz, int px) {
     if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
     const size_t p = (size_t)pz * g.pitch + px;
     const float am = md.ave_mu[p];
     if (am == 0.0f) return 0.0f;
     const double h = 1.0 / (double)md.mu[p] + 1.0 / (double)md.mu[p + g.pitch] + 1.0 / (double)md.mu[p + 1] +
                      1.0 / (double)md.mu[p + g.pitch + 1];
-    return (float)((double)(acc.xz(p) * am) / h * 1e6);
+    return (float)((double)(acc.xz[p] * am) / h * 1e6);
 }
 
-template <bool PC>
-__global__ void k_finalize_gradients(Grid g, Media md, Acc5<PC> acc, float *__restrict__ gLam, float *__restrict__ gMu,
+__global__ void k_finalize_gradients(Grid g, Media md, ImgAcc acc, float *__restrict__ gLam, float *__restrict__ gMu,
                                      float *__restrict__ gDen) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int z = blockIdx.y * blockDim.y + threadIdx.y;
@@ -928,9 +875,8 @@ __global__ void k_finalize_gradients(Grid g, Media md, Acc5<PC> acc, float *__re
         const size_t i = (size_t)z * g.pitch + x;
         const bool inside = (x <= g.xmax);
         if (inside) {
-            const f2 lm = acc.lm(i);
-            gl = (float)((double)lm.x * 1e6);
-            gm = (float)((double)lm.y * 1e6);
+            gl = (float)((double)acc.lam[i] * 1e6);
+            gm = (float)((double)acc.mu[i] * 1e6);
         }
         // A fluid cell (mu = 0) makes every corner around it a zero-average one, which sprays nothing (el_stress.cu:112: the spray
         // is inside `if (ave_Mu != 0)`); its 1/mu^2 = inf must not meet those zero weights (inf * 0 = NaN).
@@ -948,13 +894,13 @@ __global__ void k_finalize_gradients(Grid g, Media md, Acc5<PC> acc, float *__re
             if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
             const size_t p = (size_t)pz * g.pitch + px;
             const double b = md.byc_a[p];
-            return (float)((double)acc.ab(p).x * (-(b * b) / 2.0));
+            return (float)((double)acc.a[p] * (-(b * b) / 2.0));
         };
         auto B = [&](int pz, int px) -> float {
             if (pz < g.nPml || pz > g.zmax || px < g.nPml || px > g.xmax) return 0.0f;
             const size_t p = (size_t)pz * g.pitch + px;
             const double b = md.byc_b[p];
-            return (float)((double)acc.ab(p).y * (-(b * b) / 2.0));
+            return (float)((double)acc.b[p] * (-(b * b) / 2.0));
         };
         gd = A(z, x) + B(z, x) + A(z - 1, x) + B(z, x - 1);
     }
@@ -994,7 +940,6 @@ const OptField kOptFields[] = {
     {"batch_order", &KernelOptions::batch_order, 0, 1},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
-    {"pair", &KernelOptions::pair, 0, 7},         {"acc_nt", &KernelOptions::acc_nt, 0, 1},
 };
 }  // namespace
 
@@ -1027,7 +972,6 @@ static inline Grid tiled(const Grid &g0, const KernelOptions &o, int fly_bit = -
     g.rho_fly = fly_bit < 0 ? 0 : (o.rho_fly >> fly_bit) & 1;
     g.amu_fly = fly_bit < 0 ? 0 : (o.amu_fly >> fly_bit) & 1;
     g.rk_lazy = o.rk_lazy;
-    g.acc_nt = o.acc_nt;
     return g;
 }
 static inline dim3 field_grid(const Grid &g) {
@@ -1036,117 +980,73 @@ static inline dim3 field_grid(const Grid &g) {
 }
 #define BLOCK dim3(BX *g.bz)
 
-// Run-time option bits -> compile-time layout parameters.  `fn` is a generic lambda called with std::bool_constant tags.
-template <bool V> using BC = std::integral_constant<bool, V>;
-template <class Fn> static inline void with1(bool a, Fn &&fn) {
-    if (a) fn(BC<true>{}); else fn(BC<false>{});
-}
-// (forward fields paired, adjoint fields paired, accumulators paired, early loads)
-template <class Fn> static inline void with_layout(int pair, bool early, Fn &&fn) {
-    with1(pair & 1, [&](auto pf) {
-        with1(pair & 2, [&](auto pa) {
-            with1(pair & 4, [&](auto pc) { with1(early, [&](auto e) { fn(pf, pa, pc, e); }); });
-        });
-    });
-}
-static inline size_t stride_of(const Fields &f) { return (size_t)(f.vx - f.vz); }
-
 void launch_stress_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
                        float *frame_t, int z_src, int x_src, float src_amp, LineRec lr) {
     const Grid g = tiled(g0, o, 0);
-    with1(o.pair & 1, [&](auto pf) {
-        constexpr bool PF = decltype(pf)::value;
-        const F5<PF> ff{f.vz, stride_of(f)};
-        if (frame_t)
-            hipLaunchKernelGGL((k_stress<true, true, PF, false, false>), field_grid(g), BLOCK, 0, st, g, ff, m, md, pc, frame_t, z_src,
-                               x_src, src_amp, F5<false>{}, Acc5<false>{}, lr);
-        else
-            hipLaunchKernelGGL((k_stress<true, false, PF, false, false>), field_grid(g), BLOCK, 0, st, g, ff, m, md, pc, frame_t, z_src,
-                               x_src, src_amp, F5<false>{}, Acc5<false>{}, lr);
-    });
+    Fields none{};
+    ImgAcc na{};
+    if (frame_t)
+        hipLaunchKernelGGL((k_stress<true, true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
+                           x_src, src_amp, none, na, lr);
+    else
+        hipLaunchKernelGGL((k_stress<true, false>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
+                           x_src, src_amp, none, na, lr);
 }
 
 void launch_velocity_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc) {
     const Grid g = tiled(g0, o, 0);
-    with1(o.pair & 1, [&](auto pf) {
-        constexpr bool PF = decltype(pf)::value;
-        hipLaunchKernelGGL((k_velocity<true, PF, false, false>), field_grid(g), BLOCK, 0, st, g, F5<PF>{f.vz, stride_of(f)}, m, md, pc,
-                           (const float *)nullptr, -1, -1, 0.0f, (float *)nullptr, F5<false>{}, Acc5<false>{});
-    });
+    Fields none{};
+    ImgAcc na{};
+    hipLaunchKernelGGL((k_velocity<true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, (const float *)nullptr,
+                       -1, -1, 0.0f, (float *)nullptr, none, na);
 }
 
 void launch_velocity_rev(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, Media md, PmlCoef pc,
                          const float *frame_t, int z_src, int x_src, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc) {
     const Grid g = tiled(g0, o, 1);
     PmlMem nm{};
-    with_layout(o.pair, false, [&](auto pf, auto pa, auto pc_, auto) {
-        constexpr bool PF = decltype(pf)::value, PA = decltype(pa)::value, PC = decltype(pc_)::value;
-        hipLaunchKernelGGL((k_velocity<false, PF, PA, PC>), field_grid(g), BLOCK, 0, st, g, F5<PF>{f.vz, stride_of(f)}, nm, md, pc, frame_t,
-                           z_src, x_src, src_rxz, stf_grad_it, F5<PA>{adj.vz, stride_of(adj)}, Acc5<PC>{acc.lam, stride_of(f), g.acc_nt});
-    });
+    hipLaunchKernelGGL((k_velocity<false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src, x_src,
+                       src_rxz, stf_grad_it, adj, acc);
 }
 
 void launch_stress_rev(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, Media md, PmlCoef pc, float *frame_t,
                        int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc) {
     const Grid g = tiled(g0, o, 1);
     PmlMem nm{};
-    with_layout(o.pair, false, [&](auto pf, auto pa, auto pc_, auto) {
-        constexpr bool PF = decltype(pf)::value, PA = decltype(pa)::value, PC = decltype(pc_)::value;
-        hipLaunchKernelGGL((k_stress<false, false, PF, PA, PC>), field_grid(g), BLOCK, 0, st, g, F5<PF>{f.vz, stride_of(f)}, nm, md, pc,
-                           frame_t, z_src, x_src, src_amp, F5<PA>{adj.vz, stride_of(adj)}, Acc5<PC>{acc.lam, stride_of(f), g.acc_nt},
-                           LineRec{});
-    });
+    hipLaunchKernelGGL((k_stress<false, false>), field_grid(g), BLOCK, 0, st, g, f, nm, md, pc, frame_t, z_src,
+                       x_src, src_amp, adj, acc, LineRec{});
 }
 
 void launch_velocity_adj(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields adj, PmlMem m, Media md, PmlCoef pc) {
     const Grid g = tiled(g0, o, 1);
-    with1(o.pair & 2, [&](auto pa) {
-        constexpr bool PA = decltype(pa)::value;
-        hipLaunchKernelGGL(k_velocity_adj<PA>, field_grid(g), BLOCK, 0, st, g, F5<PA>{adj.vz, stride_of(adj)}, m, md, pc);
-    });
+    hipLaunchKernelGGL(k_velocity_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
 void launch_stress_adj(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields adj, PmlMem m, Media md, PmlCoef pc) {
     const Grid g = tiled(g0, o, 1);
-    with1(o.pair & 2, [&](auto pa) {
-        constexpr bool PA = decltype(pa)::value;
-        hipLaunchKernelGGL(k_stress_adj<PA>, field_grid(g), BLOCK, 0, st, g, F5<PA>{adj.vz, stride_of(adj)}, m, md, pc);
-    });
+    hipLaunchKernelGGL(k_stress_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
 void launch_bwd_a(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
                   const float *frame_t, Fields adj, ImgAcc acc) {
     const Grid g = tiled(g0, o, 1);
-    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, stride_of(f)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    with_layout(o.pair, (o.early & 1) != 0, [&](auto pf, auto pa, auto pc_, auto e) {
-        hipLaunchKernelGGL((k_bwd_a<decltype(e)::value, decltype(pf)::value, decltype(pa)::value, decltype(pc_)::value>), field_grid(g),
-                           BLOCK, 0, st, g, b, frame_t);
-    });
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
+    auto k = (o.early & 1) ? k_bwd_a<true> : k_bwd_a<false>;
+    hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
 
 void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc, float *frame_t,
                   int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
                   hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
-    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, stride_of(f)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
-    with_layout(o.pair, (o.early & 2) != 0, [&](auto pf, auto pa, auto pc_, auto e) {
-        auto k = k_bwd_b<decltype(e)::value, decltype(pf)::value, decltype(pa)::value, decltype(pc_)::value>;
-        if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
-            hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
-                                  src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
-        else
-            hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
-                               stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
-    });
-}
-
-// test hook (sepfwi_debug_field): one member of a planar (stride 1) or interleaved (stride 2) array -> dense (nzc, nx)
-__global__ void k_extract(const float *__restrict__ src, int stride, int pitch, int nx, int nzc, float *__restrict__ out) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y;
-    if (x < nx && z < nzc) out[(size_t)z * nx + x] = src[((size_t)z * pitch + x) * (size_t)stride];
-}
-void launch_extract(hipStream_t st, const float *src, int stride, const Grid &g, float *out) {
-    hipLaunchKernelGGL(k_extract, dim3((g.nx + 255) / 256, g.nzc), dim3(256), 0, st, src, stride, g.pitch, g.nx, g.nzc, out);
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
+    auto k = (o.early & 2) ? k_bwd_b<true> : k_bwd_b<false>;
+    if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
+        hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
+                              src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
+    else
+        hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
+                           stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
 __global__ void k_add_inplace(float *__restrict__ a, const float *__restrict__ b, size_t n) {
@@ -1170,59 +1070,45 @@ static inline dim3 batch_grid(const Grid &g) {
 void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                              PmlCoef pc, size_t n, size_t data_len, int it, float src_scale, bool save) {
     const Grid g = tiled_batch(g0, o, 0, nb);
-    with1(o.pair & 1, [&](auto pf) {
-        constexpr bool PF = decltype(pf)::value;
-        if (save)
-            hipLaunchKernelGGL((k_stress_fwd_batch<true, PF>), batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
-        else
-            hipLaunchKernelGGL((k_stress_fwd_batch<false, PF>), batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
-    });
+    if (save)
+        hipLaunchKernelGGL(k_stress_fwd_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
+    else
+        hipLaunchKernelGGL(k_stress_fwd_batch<false>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
 }
 void launch_velocity_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                                PmlCoef pc, size_t n) {
     const Grid g = tiled_batch(g0, o, 0, nb);
-    with1(o.pair & 1, [&](auto pf) {
-        hipLaunchKernelGGL(k_velocity_fwd_batch<decltype(pf)::value>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
-    });
+    hipLaunchKernelGGL(k_velocity_fwd_batch, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
 }
 void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it) {
     const Grid g = tiled_batch(g0, o, 1, nb);
-    with_layout(o.pair, (o.early & 1) != 0, [&](auto pf, auto pa, auto pc_, auto e) {
-        hipLaunchKernelGGL((k_bwd_a_batch<decltype(e)::value, decltype(pf)::value, decltype(pa)::value, decltype(pc_)::value>), batch_grid(g),
-                           BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
-    });
+    if (o.early & 1)
+        hipLaunchKernelGGL(k_bwd_a_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
+    else
+        hipLaunchKernelGGL(k_bwd_a_batch<false>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
 }
 void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled_batch(g0, o, 1, nb);
-    with_layout(o.pair, (o.early & 2) != 0, [&](auto pf, auto pa, auto pc_, auto e) {
-        auto k = k_bwd_b_batch<decltype(e)::value, decltype(pf)::value, decltype(pa)::value, decltype(pc_)::value>;
-        if (ev_start)
-            hipExtLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);
-        else
-            hipLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it, src_scale);
-    });
+    auto k = (o.early & 2) ? k_bwd_b_batch<true> : k_bwd_b_batch<false>;
+    if (ev_start)
+        hipExtLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);
+    else
+        hipLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it, src_scale);
 }
 
-void launch_record(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
+void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps, const float *sens) {
     if (nrec <= 0) return;
-    with1(o.pair & 1, [&](auto pf) {
-        constexpr bool PF = decltype(pf)::value;
-        hipLaunchKernelGGL(k_record<PF>, dim3((nrec + 255) / 256), dim3(256), 0, st, g, F5<PF>{f.vz, stride_of(f)}, nrec, rec_idx, d_pr,
-                           d_vx, d_vz, d_ett, comps, g.fiber, sens);
-    });
+    hipLaunchKernelGGL(k_record, dim3((nrec + 255) / 256), dim3(256), 0, st, g, f, nrec, rec_idx, d_pr, d_vx, d_vz, d_ett,
+                       comps, g.fiber, sens);
 }
 
-void launch_inject(hipStream_t st, const Grid &g, const KernelOptions &o, Fields adj, int nrec, const int *rec_idx, const float *res_t,
-                   const float *sens) {
+void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const int *rec_idx, const float *res_t, const float *sens) {
     if (nrec <= 0) return;
-    with1(o.pair & 2, [&](auto pa) {
-        constexpr bool PA = decltype(pa)::value;
-        hipLaunchKernelGGL(k_inject<PA>, dim3((nrec + 255) / 256), dim3(256), 0, st, F5<PA>{adj.vz, stride_of(adj)}, nrec, rec_idx, res_t,
-                           g.fiber ? g.pitch : 0, sens, g.pitch, g.dx * g.rdz);
-    });
+    hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t, g.fiber ? g.pitch : 0,
+                       sens, g.pitch, g.dx * g.rdz);
 }
 
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
@@ -1245,13 +1131,10 @@ void launch_model_prep(hipStream_t st, const Grid &g, const KernelOptions &o, co
                        lam, mu, ave_mu, byc_a, byc_b, rho, cp2_max_bits, o.amu_fly != 0 ? 1 : 0);
 }
 
-void launch_finalize_gradients(hipStream_t st, const Grid &g, const KernelOptions &o, Media md, ImgAcc acc, float *gLam, float *gMu,
+void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
                                float *gDen) {
-    with1(o.pair & 4, [&](auto pc_) {
-        constexpr bool PC = decltype(pc_)::value;
-        hipLaunchKernelGGL(k_finalize_gradients<PC>, dim3((g.nx + 63) / 64, (g.nz + 3) / 4), dim3(64, 4), 0, st, g, md,
-                           Acc5<PC>{acc.lam, (size_t)(acc.mu - acc.lam), 0}, gLam, gMu, gDen);
-    });
+    hipLaunchKernelGGL(k_finalize_gradients, dim3((g.nx + 63) / 64, (g.nz + 3) / 4), dim3(64, 4), 0, st, g, md, acc, gLam,
+                       gMu, gDen);
 }
 
 }  // namespace sepfwi

@@ -25,10 +25,6 @@ struct KernelOptions {
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
-    int pair = 0;         // array layouts (pure layout, results bit-identical): bit 0 the five forward fields, bit 1 the five adjoint fields,
-                          // bit 2 the five imaging accumulators hold the members that are always tapped together interleaved
-                          // ((vz,vx), (szz,sxx), (lam,mu), (a,b)): one 8-byte load per lane instead of two 4-byte ones
-    int acc_nt = 0;       // 1: non-temporal loads / stores for the imaging accumulators (touched exactly once per time step)
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)
 };
@@ -59,12 +55,11 @@ void launch_bwd_a_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it);
 void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-void launch_extract(hipStream_t st, const float *src, int stride, const Grid &g, float *out);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
-void launch_record(hipStream_t st, const Grid &g, const KernelOptions &o, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
+void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps, const float *sens = nullptr);
 // sens: null (straight fibre along x, or along z when g.fiber) or nrec x 3 directional sensitivities (s_xx, s_zz, s_xz)
-void launch_inject(hipStream_t st, const Grid &g, const KernelOptions &o, Fields adj, int nrec, const int *rec_idx, const float *res_t,
+void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const int *rec_idx, const float *res_t,
                    const float *sens = nullptr);
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
                      double *sumsq);
@@ -72,7 +67,7 @@ void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int
 void launch_model_prep(hipStream_t st, const Grid &g, const KernelOptions &o, const float *Lam_in, const float *Mu_in,
                        const float *Den_in, float *lam, float *mu, float *ave_mu, float *byc_a, float *byc_b, float *rho,
                        unsigned int *cp2_max_bits);
-void launch_finalize_gradients(hipStream_t st, const Grid &g, const KernelOptions &o, Media md, ImgAcc acc, float *gLam, float *gMu,
+void launch_finalize_gradients(hipStream_t st, const Grid &g, Media md, ImgAcc acc, float *gLam, float *gMu,
                                float *gDen);
 
 }  // namespace sepfwi

@@ -632,13 +632,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         launches_ += 2;
         if (!inl) {
             const size_t col = (size_t)(it + 1) * c.nrec;
-            launch_record(c.st, g, opt, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
+            launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
             launches_++;
         }
     };
     auto forward_last_column = [&](const ShotCtx &c) {
         const size_t col = (size_t)(nSteps - 1) * c.nrec;
-        launch_record(c.st, g, opt, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
+        launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
         launches_++;
     };
     auto residual = [&](const ShotCtx &c) {
@@ -762,13 +762,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         if (fuse_bwd == 2) {
             launch_bwd_a(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
             launch_bwd_b(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
-            if (!inj_inl) launch_inject(L.s, g, opt, L.adj, c.nrec, c.rec, res_t, c.sens);
+            if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
             launches_ += inj_inl ? 2 : 3;
         } else {  // the reference's launch structure
             launch_velocity_rev(L.s, gs, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
             launch_stress_rev(L.s, gs, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
             launch_velocity_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
-            launch_inject(L.s, g, opt, L.adj, c.nrec, c.rec, res_t, c.sens);
+            launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
             launch_stress_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
             launches_ += 5;
         }
@@ -806,7 +806,6 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     const bool batched = fuse_bwd == 2 && group_size >= 1 &&
                          (opt.batch == 1 || (opt.batch == 2 && (withAdj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
     last_batched_ = batched;
-    last_pair_ = opt.pair;
     if (batched) {
         if (opt.batch_f > 0) Bf = opt.batch_f;
         if (opt.batch_b > 0) Bb = opt.batch_b;
@@ -872,7 +871,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                     if (!(tab[is0 + k].comps & 16)) {  // general receivers: sample the new state into column it+1
                         const ShotCtx &c = cx[k];
                         const size_t col = (size_t)(it + 1) * c.nrec;
-                        launch_record(st, g, opt, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
+                        launch_record(st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
                         launches_++;
                     }
             }
@@ -916,7 +915,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                         if (tab[is0 + kb + k].lr_n == 0) {
                             const ShotCtx &c = cx[kb + k];
                             const Fields adj = Fields{bl_[k].bwd + 8 * n, bl_[k].bwd + 9 * n, bl_[k].bwd + 10 * n, bl_[k].bwd + 11 * n, bl_[k].bwd + 12 * n};
-                            launch_inject(st, g, opt, adj, c.nrec, c.rec, c.res + (size_t)it * c.nrec, c.sens);
+                            launch_inject(st, g, adj, c.nrec, c.rec, c.res + (size_t)it * c.nrec, c.sens);
                             launches_++;
                         }
                 }
@@ -991,7 +990,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     if (withAdj) {
         const bool devL = ptr_device(grad_Lambda) == gpu_id_, devM = ptr_device(grad_Mu) == gpu_id_, devD = ptr_device(grad_Den) == gpu_id_;
         float *oL = devL ? grad_Lambda : grad_stage_, *oM = devM ? grad_Mu : grad_stage_ + dense, *oD = devD ? grad_Den : grad_stage_ + 2 * dense;
-        launch_finalize_gradients(st, g, opt, md_, acc_, oL, oM, oD);
+        launch_finalize_gradients(st, g, md_, acc_, oL, oM, oD);
         launches_++;
         if (!devL) HIP_OK(hipMemcpyAsync(grad_Lambda, oL, dense * sizeof(float), hipMemcpyDefault, st));
         if (!devM) HIP_OK(hipMemcpyAsync(grad_Mu, oM, dense * sizeof(float), hipMemcpyDefault, st));
@@ -1020,33 +1019,23 @@ void Session::copy_field(int lane, int which, float *out) {
     std::lock_guard<std::mutex> lock(mu_);
     HIP_OK(hipSetDevice(gpu_id_));
     if (!out || which < 0 || which > 9) throw std::invalid_argument("debug_field: which must be 0..9");
-    const float *base = nullptr;  // the block of five arrays that holds the field
+    const float *base = nullptr;
     if (which >= 5) {  // adjoint fields: one set per session (stream mode) or per backward lane (batched mode)
         if (last_batched_) {
             if (lane < 0 || lane >= (int)bl_.size() || !bl_[lane].bwd) throw std::invalid_argument("debug_field: no such backward lane");
-            base = bl_[lane].bwd + 8 * cells_;
+            base = bl_[lane].bwd + (8 + (which - 5)) * cells_;
         } else {
-            base = adj_.vz;
+            base = adj_.vz + (size_t)(which - 5) * cells_;
         }
     } else if (last_batched_) {
         if (lane < 0 || lane >= (int)bl_.size() || !bl_[lane].state) throw std::invalid_argument("debug_field: no such lane");
-        base = bl_[lane].state;
+        base = bl_[lane].state + (size_t)which * cells_;
     } else {
         if (lane < 0 || lane >= kMaxLanes || (lane > 0 && !xl_[lane].state)) throw std::invalid_argument("debug_field: no such lane");
-        base = lane ? xl_[lane].state : state_;
+        base = (lane ? xl_[lane].state : state_) + (size_t)which * cells_;
     }
-    // member `m` of the block: planar [vz|vx|szz|sxx|sxz], or with option "pair" [(vz,vx) | (szz,sxx) | sxz] (device_common.hpp F5)
-    const int m = which % 5;
-    const bool paired = (last_pair_ >> (which >= 5 ? 1 : 0)) & 1;
-    const float *src = base + (size_t)m * cells_;
-    int stride = 1;
-    if (paired && m < 4) {
-        src = base + (size_t)(m / 2) * 2 * cells_ + (m & 1);
-        stride = 2;
-    }
-    launch_extract(own_stream_, src, stride, g_, grad_stage_);
-    HIP_OK(hipStreamSynchronize(own_stream_));
-    HIP_OK(hipMemcpy(out, grad_stage_, (size_t)g_.nx * (size_t)g_.nzc * sizeof(float), hipMemcpyDefault));
+    HIP_OK(hipMemcpy2D(out, (size_t)g_.nx * sizeof(float), base, (size_t)g_.pitch * sizeof(float), (size_t)g_.nx * sizeof(float),
+                       (size_t)g_.nzc, hipMemcpyDefault));
 }
 
 void Session::stats(sepfwi_stats *out) const {

@@ -97,7 +97,6 @@ class Session {
     float *d_stf_ = nullptr;
     size_t d_stf_len_ = 0;
     bool last_batched_ = false;
-    int last_pair_ = 0;  // option "pair" of the last call: how sepfwi_debug_field has to read the field blocks
     float *state_ = nullptr, *media_ = nullptr, *acc_buf_ = nullptr, *in_stage_ = nullptr, *grad_stage_ = nullptr;
     float *frame_ = nullptr, *syn_ = nullptr, *res_ = nullptr, *xpose_ = nullptr, *stf_grad_ = nullptr, *h_io_ = nullptr;
     double *scal_ = nullptr;
