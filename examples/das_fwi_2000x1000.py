@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--scipy-minimize", action="store_true",
                     help="go through optimize.minimize() as the reference's scripts do instead of sepfwi.obj_wrapper.minimize_lbfgsb\n"
                          "(same routine, same iterates; 10-20 s more per call on 6 M bounded unknowns)")
+    ap.add_argument("--pert", type=float, default=0.1, help="amplitude of the true model's random perturbation (bench.marmousi_style: 0.1)")
+    ap.add_argument("--sigma-init", type=float, default=40.0, help="Gaussian smoothing [cells] that makes the initial model from the true one (40)")
+    ap.add_argument("--step0", type=float, default=20.0, help="largest model change [m/s, kg/m^3] of L-BFGS-B's first trial step (objective scaling)")
+    ap.add_argument("--files", action="store_true", help="observed data through Shot_*.bin files as the reference does (default: straight into the HBM store)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend under torchrun (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0: rehearsal of the N-rank run on a one-GPU box (with --backend gloo)")
     a = ap.parse_args()
@@ -99,15 +103,16 @@ def main():
     work = tempfile.mkdtemp(prefix="sepfwi_fwi_r%d_" % rank)
     nPml = 32
     nPad = ft.nPad_for(a.nz, nPml)
-    pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, a.shots)
-    true, init = bench.marmousi_style(a.nz, a.nx)
+    pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, a.shots, pert_amp=a.pert, sigma_init=a.sigma_init)
+    true, init = bench.marmousi_style(a.nz, a.nx, pert_amp=a.pert, sigma_init=a.sigma_init)
     Stf = pb["Stf"].to(dev)
     Shot_ids = torch.arange(a.shots, dtype=torch.int32)
     opt = dict(nz=a.nz, nx=a.nx, nz_orig=a.nz, nx_orig=a.nx, nPml=nPml, nPad=nPad, para_fname=pb["para_fname"])
 
     t0 = time.perf_counter()
     pad = lambda m: torch.tensor(ft.padding_numpy_array(m, nPml, nPad), dtype=torch.float32, device=dev)
-    M.FWI_obscalc(pad(true[0]), pad(true[1]), pad(true[2]), Stf, pb["para_fname"])(Shot_ids, ngpu=1)
+    # observed data: modelled from the true model straight into the sessions' HBM store (no Shot_*.bin files: 127 MB per shot)
+    M.FWI_obscalc(pad(true[0]), pad(true[1]), pad(true[2]), Stf, pb["para_fname"])(Shot_ids, ngpu=1, to_store=not a.files)
     torch.cuda.synchronize()
     t_obs = time.perf_counter() - t0
 
@@ -141,7 +146,7 @@ def main():
     # L-BFGS-B starts a bounded problem with the full step x - g: scale the objective so that this first step changes
     # the model by at most 20 (m/s, kg/m^3).  (The scaling has to sit here: FWIFunction.backward ignores grad_misfit,
     # as in the reference, FWI_ops.py:54-63.)
-    c = 20.0 / float(np.abs(g0).max())
+    c = a.step0 / float(np.abs(g0).max())
     if rank == 0:
         print("observed data: %.2f s   iterate 0: misfit %.6e  |g|_inf %.3e  (%.2f s per gradient evaluation, %d shots on "
               "%d GPU(s))" % (t_obs, f0, np.abs(g0).max(), evals[-1], a.shots, world), flush=True)

@@ -30,6 +30,10 @@ extern "C" {
 #define SEPFWI_CALC_MISFIT 0   /* forward + residual -> misfit                      */
 #define SEPFWI_CALC_GRADIENT 1 /* + boundary saving, adjoint, gradients             */
 #define SEPFWI_CALC_OBSERVE 2  /* forward only, write Shot_{pr,vx,vz,ett}{id}.bin   */
+/* Extension (no counterpart in the reference): forward only, and the axial-strain gather of every shot goes straight into the
+ * session's HBM store of observed data -- what SEPFWI_CALC_OBSERVE followed by reading Shot_ett{id}.bin back would leave there,
+ * bit for bit, without the four files per shot (synthetic studies, benchmarks).  No other output. */
+#define SEPFWI_CALC_OBSERVE_TO_STORE 3
 
 /* Message of the last failure on the calling thread (never NULL). */
 const char *sepfwi_last_error(void);

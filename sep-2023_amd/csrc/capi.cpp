@@ -61,7 +61,7 @@ int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float 
                        int gpu_id, int group_size, const int *shot_ids, const char *para_fname, void *hip_stream,
                        int async) {
     return guarded([&] {
-        if (calc_id < 0 || calc_id > 2) throw std::invalid_argument("Invalid calc_id " + std::to_string(calc_id));  // libCUFD.cu:43-46
+        if (calc_id < 0 || calc_id > 3) throw std::invalid_argument("Invalid calc_id " + std::to_string(calc_id));  // libCUFD.cu:43-46
         if (!para_fname) throw std::invalid_argument("para_fname is NULL");
         if (!Lambda || !Mu || !Den || !stf) throw std::invalid_argument("Lambda, Mu, Den and stf must not be NULL");
         if (group_size < 0 || (group_size > 0 && !shot_ids)) throw std::invalid_argument("bad shot list");

@@ -9,8 +9,9 @@
 // applied to the axial-strain gathers (the component that enters misfit and adjoint source, libCUFD.cu:427,607).  Traces
 // are processed in the files' [rec][it] layout.  Parity for this extension is against the numpy restatement in
 // oracle/oracle.py (cond_window, cond_bandpass, conditioned_residual); the reference offers no run of it to pin on.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <hipfft/hipfft.h>
+#include <hipfft/hipfft.h>  // types and enumerators only: the library itself is opened on first use (FftApi below)
 
 #include <stdexcept>
 #include <string>
@@ -176,6 +177,38 @@ __global__ void k_apply_coef(int nf, int nrec, hipfftComplex *__restrict__ spec,
     v.y = y;
 }
 
+// hipFFT is only needed by a parameter file with a band-pass or a source-signature update, so libsepfwi.so does not link it:
+// the five entry points are resolved with dlopen when the first plan is made, and a ROCm image without hipFFT still loads and
+// runs the propagator (a parameter file that asks for a filter then fails with a message that names the library).
+struct FftApi {
+    hipfftResult (*Plan1d)(hipfftHandle *, int, hipfftType, int);
+    hipfftResult (*SetStream)(hipfftHandle, hipStream_t);
+    hipfftResult (*ExecR2C)(hipfftHandle, hipfftReal *, hipfftComplex *);
+    hipfftResult (*ExecC2R)(hipfftHandle, hipfftComplex *, hipfftReal *);
+    hipfftResult (*Destroy)(hipfftHandle);
+};
+const FftApi &fft() {
+    static const FftApi api = [] {
+        void *h = nullptr;
+        for (const char *name : {"libhipfft.so.0", "libhipfft.so", "/opt/rocm/lib/libhipfft.so.0"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) throw std::runtime_error("data conditioning (filter / if_src_update) needs hipFFT, and libhipfft.so could not be opened");
+        FftApi a{};
+        auto sym = [&](const char *n) {
+            void *p = dlsym(h, n);
+            if (!p) throw std::runtime_error(std::string("libhipfft.so lacks ") + n);
+            return p;
+        };
+        a.Plan1d = (decltype(a.Plan1d))sym("hipfftPlan1d");
+        a.SetStream = (decltype(a.SetStream))sym("hipfftSetStream");
+        a.ExecR2C = (decltype(a.ExecR2C))sym("hipfftExecR2C");
+        a.ExecC2R = (decltype(a.ExecC2R))sym("hipfftExecC2R");
+        a.Destroy = (decltype(a.Destroy))sym("hipfftDestroy");
+        return a;
+    }();
+    return api;
+}
+
 void fft_ok(hipfftResult r, const char *what) {
     if (r != HIPFFT_SUCCESS) throw std::runtime_error(std::string("hipFFT failure in ") + what + " (code " + std::to_string((int)r) + ")");
 }
@@ -191,8 +224,8 @@ Conditioner::Conditioner(int nt, int max_nrec) : nt_(nt), cap_(max_nrec) {
 
 Conditioner::~Conditioner() {
     for (auto &kv : plans_) {
-        (void)hipfftDestroy((hipfftHandle)kv.second.fwd);
-        (void)hipfftDestroy((hipfftHandle)kv.second.inv);
+        (void)fft().Destroy((hipfftHandle)kv.second.fwd);
+        (void)fft().Destroy((hipfftHandle)kv.second.inv);
     }
     (void)hipFree(pad_);
     (void)hipFree(spec_);
@@ -223,11 +256,11 @@ void Conditioner::bandpass(hipStream_t st, float *data, int nrec, float dt, cons
     Plans &pl = plans_for(nrec, st);
     hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;
     hipLaunchKernelGGL(k_embed, dim3((npad + 255) / 256, nrec), dim3(256), 0, st, nt_, nrec, data, pad_);
-    fft_ok(hipfftExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
+    fft_ok(fft().ExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
     const float df = (float)(1.0 / (double)dt / (double)npad);
     hipLaunchKernelGGL(k_bp_filter, dim3((nf + 255) / 256, nrec), dim3(256), 0, st, nf, nrec, df, filt[0], filt[1], filt[2], filt[3],
                        (hipfftComplex *)spec_);
-    fft_ok(hipfftExecC2R(b, (hipfftComplex *)spec_, pad_), "hipfftExecC2R");
+    fft_ok(fft().ExecC2R(b, (hipfftComplex *)spec_, pad_), "hipfftExecC2R");
     hipLaunchKernelGGL(k_crop, dim3((nt_ + 255) / 256, nrec), dim3(256), 0, st, nt_, nrec, data, pad_, 1.0f / (float)npad);
 }
 
@@ -236,8 +269,8 @@ Conditioner::Plans &Conditioner::plans_for(int nrec, hipStream_t st) {
     if (it == plans_.end()) {
         Plans p{};
         hipfftHandle f, b;
-        fft_ok(hipfftPlan1d(&f, 2 * nt_, HIPFFT_R2C, nrec), "hipfftPlan1d(R2C)");
-        fft_ok(hipfftPlan1d(&b, 2 * nt_, HIPFFT_C2R, nrec), "hipfftPlan1d(C2R)");
+        fft_ok(fft().Plan1d(&f, 2 * nt_, HIPFFT_R2C, nrec), "hipfftPlan1d(R2C)");
+        fft_ok(fft().Plan1d(&b, 2 * nt_, HIPFFT_C2R, nrec), "hipfftPlan1d(C2R)");
         p.fwd = (void *)f;
         p.inv = (void *)b;
         // Plan creation is not stream-ordered (rocFFT may build its tables with work of its own on the null stream), and the
@@ -246,8 +279,8 @@ Conditioner::Plans &Conditioner::plans_for(int nrec, hipStream_t st) {
         if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("conditioning: hipDeviceSynchronize failed");
         it = plans_.emplace(nrec, p).first;
     }
-    fft_ok(hipfftSetStream((hipfftHandle)it->second.fwd, st), "hipfftSetStream");
-    fft_ok(hipfftSetStream((hipfftHandle)it->second.inv, st), "hipfftSetStream");
+    fft_ok(fft().SetStream((hipfftHandle)it->second.fwd, st), "hipfftSetStream");
+    fft_ok(fft().SetStream((hipfftHandle)it->second.inv, st), "hipfftSetStream");
     return it->second;
 }
 
@@ -279,11 +312,11 @@ void Conditioner::source_update(hipStream_t st, const float *obs, float *syn, in
     // cuda_window over the PADDED length, ratio 0.01 (utilities.cu:1199-1202)
     hipLaunchKernelGGL(k_window, gpad, blk, 0, st, npad, nrec, dt, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1.0f, 0.01f, pad_);
     hipLaunchKernelGGL(k_window, gpad, blk, 0, st, npad, nrec, dt, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1.0f, 0.01f, pad2_);
-    fft_ok(hipfftExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
-    fft_ok(hipfftExecR2C(f, pad2_, (hipfftComplex *)spec2_), "hipfftExecR2C");
+    fft_ok(fft().ExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
+    fft_ok(fft().ExecR2C(f, pad2_, (hipfftComplex *)spec2_), "hipfftExecR2C");
     hipLaunchKernelGGL(k_matching_coef, dim3(nf), blk, 0, st, nf, nrec, (const hipfftComplex *)spec_, (const hipfftComplex *)spec2_, (hipfftComplex *)coef_);
     hipLaunchKernelGGL(k_apply_coef, dim3((nf + 255) / 256, nrec), blk, 0, st, nf, nrec, (hipfftComplex *)spec2_, (const hipfftComplex *)coef_, 0);
-    fft_ok(hipfftExecC2R(b, (hipfftComplex *)spec2_, pad2_), "hipfftExecC2R");
+    fft_ok(fft().ExecC2R(b, (hipfftComplex *)spec2_, pad2_), "hipfftExecC2R");
     hipLaunchKernelGGL(k_crop, dim3((nt_ + 255) / 256, nrec), blk, 0, st, nt_, nrec, syn, pad2_, 1.0f / (float)npad);
 }
 
@@ -296,9 +329,9 @@ void Conditioner::source_update_adj(hipStream_t st, float *res, int nrec, float 
     hipfftHandle f = (hipfftHandle)pl.fwd, b = (hipfftHandle)pl.inv;
     const dim3 gpad((npad + 255) / 256, nrec), blk(256);
     hipLaunchKernelGGL(k_embed, gpad, blk, 0, st, nt_, nrec, (const float *)res, pad_);
-    fft_ok(hipfftExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
+    fft_ok(fft().ExecR2C(f, pad_, (hipfftComplex *)spec_), "hipfftExecR2C");
     hipLaunchKernelGGL(k_apply_coef, dim3((nf + 255) / 256, nrec), blk, 0, st, nf, nrec, (hipfftComplex *)spec_, (const hipfftComplex *)coef_, 1);
-    fft_ok(hipfftExecC2R(b, (hipfftComplex *)spec_, pad_), "hipfftExecC2R");
+    fft_ok(fft().ExecC2R(b, (hipfftComplex *)spec_, pad_), "hipfftExecC2R");
     hipLaunchKernelGGL(k_window, gpad, blk, 0, st, npad, nrec, dt, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1.0f, 0.01f, pad_);
     hipLaunchKernelGGL(k_crop, dim3((nt_ + 255) / 256, nrec), blk, 0, st, nt_, nrec, res, pad_, 1.0f / (float)npad);
 }

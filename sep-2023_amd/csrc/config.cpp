@@ -46,6 +46,16 @@ Params parse_params(const std::string &text) {
         if (!(p.filter[0] <= p.filter[1] && p.filter[1] <= p.filter[2] && p.filter[2] <= p.filter[3]))
             throw std::runtime_error("parameter JSON: filter corners must be ascending");
     }
+    p.if_win_key = p.if_win;
+    if (j.has("conditioning")) {
+        const std::string c = j.at("conditioning").as_string("conditioning");
+        if (c == "reference") {
+            p.conditioning_reference = true;
+            p.if_win = p.if_src_update = p.if_cross_misfit = p.has_filter = false;
+        } else if (c != "live") {
+            throw std::runtime_error("parameter JSON: conditioning must be \"live\" or \"reference\"");
+        }
+    }
     if (j.has("das_fiber")) {
         const std::string f = j.at("das_fiber").as_string("das_fiber");
         if (f == "vertical")

@@ -17,6 +17,11 @@ struct Params {
     std::string obs_pack_fname;
     // data-conditioning keys (dormant in the reference's driver, libCUFD.cu:353-457; live here, csrc/conditioning.hip)
     bool if_win = false, if_src_update = false, if_cross_misfit = false, has_filter = false;
+    // optional key "conditioning": "live" (default) -- the four keys above switch their stage on; "reference" -- they are parsed
+    // and validated like the reference does and then IGNORED like its driver does (every call site commented out,
+    // libCUFD.cu:353-457): results are those of a file without them.  if_win_key keeps what the file said, because the survey
+    // file must carry win_start / win_end whenever if_win is set, used or not (Src_Rec.cu:144-174).
+    bool conditioning_reference = false, if_win_key = false;
     float filter[4] = {0, 0, 0, 0};  // band-pass corner frequencies [Hz]   (Parameter.cpp:147-159)
     // optional key "das_fiber": "horizontal" (default; recording_exx / res_injection_exx, libCUFD.cu:325,607) or
     // "vertical" (recording_ezz / res_injection_ezz, utilities.cu:620-641 -- in the reference a source edit)

@@ -484,6 +484,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     const Grid &g = g_;
     const bool if_res = (calc_id == 0 || calc_id == 1);  // Parameter.cpp:125-137
     const bool withAdj = (calc_id == 1);
+    const bool to_store = (calc_id == SEPFWI_CALC_OBSERVE_TO_STORE);  // observe, but into the HBM store instead of the four files
     const int nSteps = par_.nSteps;
     const size_t n = cells_;
     const size_t dense = (size_t)par_.nz * (size_t)par_.nx;
@@ -587,7 +588,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         c.stf_s = stf_rows.data() + (size_t)is * nSteps;
         c.d_obs = if_res ? observed_ett(c.id, c.nrec, st) : nullptr;
         c.scratch = withAdj && !par_.scratch_dir_name.empty();  // libCUFD.cu:732-752
-        c.comps = if_res ? (c.scratch ? 9 : 8) : 15;
+        c.comps = (if_res || to_store) ? (c.scratch ? 9 : 8) : 15;
         // horizontal line of consecutive channels inside the computed region?
         const Shot &sh = *c.sh;
         bool is_line = par_.fiber == 0 && !c.sens && c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
@@ -686,6 +687,38 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
             device_bytes_ -= (long long)oit->second.bytes;
             obs_.erase(oit);
         }
+    };
+    // observe into the store (calc_id 3): the modelled axial-strain gather becomes the shot's observed data exactly as
+    // sepfwi_set_observed would install the Shot_ett file of calc_id 2 -- the device gather is already in the store's time-major layout
+    auto store_gather = [&](const ShotCtx &c) {
+        const size_t want = (size_t)c.nrec * (size_t)nSteps * sizeof(float);
+        ObsEntry e;
+        auto oit = obs_.find(c.id);
+        if (oit != obs_.end()) {
+            e = oit->second;
+            if (e.bytes != want) {
+                (void)hipFree(e.d_ett);
+                device_bytes_ -= (long long)e.bytes;
+                e.d_ett = nullptr;
+            }
+        }
+        if (c.nrec > 0 && !e.d_ett) {
+            HIP_OK(dev_malloc((void **)&e.d_ett, want));
+            device_bytes_ += (long long)want;
+        }
+        e.bytes = want;
+        e.from_memory = true;
+        if (c.nrec > 0) {
+            if (cond_on_) {  // kept conditioned and trace-major
+                launch_transpose(st, syn_of(c, 3), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
+                condition_gather(st, xpose_, c.id, c.nrec);
+                HIP_OK(hipMemcpyAsync(e.d_ett, xpose_, want, hipMemcpyDeviceToDevice, st));
+            } else {
+                HIP_OK(hipMemcpyAsync(e.d_ett, syn_of(c, 3), want, hipMemcpyDeviceToDevice, st));
+            }
+            HIP_OK(hipStreamSynchronize(st));
+        }
+        obs_[c.id] = e;
     };
     auto scratch_dumps = [&](const ShotCtx &c) {
         // optional scratch dumps of the PRESSURE component, [nrec][nSteps] float32 (libCUFD.cu:732-745):
@@ -888,7 +921,9 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
                 fwd_ms_ += ms;
             }
             for (int k = 0; k < nb; k++) {
-                if (!if_res) {
+                if (to_store) {
+                    store_gather(cx[k]);
+                } else if (!if_res) {
                     export_gathers(cx[k]);
                 } else if (cx[k].scratch) {
                     scratch_dumps(cx[k]);
@@ -970,7 +1005,9 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
 
         for (int k = 0; k < np; k++) {
-            if (!if_res) {
+            if (to_store) {
+                store_gather(ctx[k]);
+            } else if (!if_res) {
                 export_gathers(ctx[k]);
             } else if (ctx[k].scratch) {
                 scratch_dumps(ctx[k]);
@@ -1068,7 +1105,7 @@ std::shared_ptr<Session> get_session(const std::string &para_fname, int gpu_id) 
     auto it = g_sessions.find(key);
     if (it != g_sessions.end() && it->second->matches(ptext, stext)) return it->second;
     if (it != g_sessions.end()) g_sessions.erase(it);  // a thread still inside run() keeps its own reference
-    Survey sv = parse_survey(stext, par.nPml, par.if_win);
+    Survey sv = parse_survey(stext, par.nPml, par.if_win_key);
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (gpu_id < 0 || gpu_id >= ndev)

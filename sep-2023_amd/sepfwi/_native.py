@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -ffp-contract=off: no fused multiply-adds chosen per kernel by the compiler, so every kernel structure (stream, batched,
     # unfused, persistent) gives bit-identical results; the kernels are memory-bound, it costs nothing
     extra = os.environ.get("SEPFWI_HIPCC_FLAGS", "").split()   # experiments only (e.g. -fgpu-flush-denormals-to-zero)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + extra + ["-o", LIB_PATH] + SOURCES + ["-lhipfft"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + extra + ["-o", LIB_PATH] + SOURCES + ["-ldl"]   # hipFFT is opened lazily (csrc/conditioning.hip)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

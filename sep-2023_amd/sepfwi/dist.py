@@ -58,6 +58,49 @@ def fused_view(misfit, gL, gM, gD):
     return torch.as_strided(gL, (3 * n + 1,), (1,), o)
 
 
+# Record of the collectives issued by allreduce_gradients since the last reset: what a driver needs to verify that the
+# backend really saw N ranks and what the one collective per operator call cost (bench.py prints it as "rccl": {...}).
+_coll = {"calls": 0, "bytes": 0, "host_ms": 0.0, "events": [], "staged": 0}
+
+
+def _timed_all_reduce(buf):
+    """all_reduce(SUM) of one fused buffer, timed: a HIP-event pair on the current stream around the call for device buffers
+    (the stream waits for the collective, so the pair brackets it; resolved later, no synchronisation here), wall time for
+    host buffers (gloo is synchronous)."""
+    import time
+    _coll["calls"] += 1
+    _coll["bytes"] = int(buf.numel() * buf.element_size())
+    if buf.is_cuda:
+        with torch.cuda.device(buf.device):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            td.all_reduce(buf, op=td.ReduceOp.SUM)
+            e1.record()
+        if len(_coll["events"]) < 4096:
+            _coll["events"].append((e0, e1))
+    else:
+        t0 = time.perf_counter()
+        td.all_reduce(buf, op=td.ReduceOp.SUM)
+        _coll["host_ms"] += 1e3 * (time.perf_counter() - t0)
+
+
+def collective_stats(reset=False):
+    """{"ranks", "backend", "calls", "bytes", "allreduce_ms", "staged"}: calls and mean time of the gradient all-reduce since the last
+    reset, bytes of one call's buffer (4 * (3 nz nx + 1)), how many calls had to stage a copy.  Synchronises the device the
+    events were recorded on."""
+    ms, n_ev = _coll["host_ms"], 0
+    for e0, e1 in _coll["events"]:
+        e1.synchronize()
+        ms += e0.elapsed_time(e1)
+        n_ev += 1
+    timed = n_ev if n_ev else _coll["calls"]
+    out = {"ranks": world_size(), "backend": (td.get_backend() if (td.is_available() and td.is_initialized()) else None),
+           "calls": _coll["calls"], "bytes": _coll["bytes"], "allreduce_ms": (ms / timed if timed else None), "staged": _coll["staged"]}
+    if reset:
+        _coll.update(calls=0, bytes=0, host_ms=0.0, events=[], staged=0)
+    return out
+
+
 def allreduce_gradients(misfit, gL, gM, gD):
     """Sum [gLambda | gMu | gDen | misfit] over ranks with ONE collective, in place.  On the production path (RCCL, model in
     HBM) the four tensors are views of the one buffer the session wrote, which is handed to all_reduce as it is: no staging
@@ -68,18 +111,19 @@ def allreduce_gradients(misfit, gL, gM, gD):
     want = "cuda" if backend == "nccl" else "cpu"     # RCCL reduces device buffers, gloo host buffers
     fused = fused_view(misfit, gL, gM, gD)
     if fused is not None and fused.device.type == want:
-        td.all_reduce(fused, op=td.ReduceOp.SUM)
+        _timed_all_reduce(fused)
         return misfit, gL, gM, gD
+    _coll["staged"] += 1
     use_dev = torch.device("cuda", local_device_index()) if want == "cuda" else torch.device("cpu")
     if want == "cuda" and gL.is_cuda:
         use_dev = gL.device
     if fused is not None:
         stage = fused.to(use_dev)
-        td.all_reduce(stage, op=td.ReduceOp.SUM)
+        _timed_all_reduce(stage)
         fused.copy_(stage)
         return misfit, gL, gM, gD
     stage = torch.cat([gL.reshape(-1).to(use_dev), gM.reshape(-1).to(use_dev), gD.reshape(-1).to(use_dev), misfit.reshape(-1)[:1].to(use_dev)])
-    td.all_reduce(stage, op=td.ReduceOp.SUM)
+    _timed_all_reduce(stage)
     gL.copy_(stage[0:n].view_as(gL))
     gM.copy_(stage[n:2 * n].view_as(gM))
     gD.copy_(stage[2 * n:3 * n].view_as(gD))

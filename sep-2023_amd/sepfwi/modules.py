@@ -247,6 +247,10 @@ class FWI_obscalc(nn.Module):
         self.Stf = Stf
         self.para_fname = para_fname
 
-    def forward(self, Shot_ids, ngpu=1):
+    def forward(self, Shot_ids, ngpu=1, to_store=False):
+        """to_store=True: the gathers go into the sessions' HBM store of observed data instead of the Shot_*.bin files (extension)."""
         from . import ops as _ops
-        _ops.fwi_ops.obscalc(self.Lambda, self.Mu, self.Den, self.Stf, ngpu, Shot_ids, self.para_fname)
+        if to_store:
+            _ops.fwi_ops.obscalc(self.Lambda, self.Mu, self.Den, self.Stf, ngpu, Shot_ids, self.para_fname, to_store=True)
+        else:
+            _ops.fwi_ops.obscalc(self.Lambda, self.Mu, self.Den, self.Stf, ngpu, Shot_ids, self.para_fname)

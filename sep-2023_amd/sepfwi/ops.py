@@ -168,22 +168,26 @@ class _FwiOps:
                            Lambda, Mu, Den, Stf, ids, para_fname)
         return [m]
 
-    def obscalc(self, Lambda, Mu, Den, Stf, ngpu, Shot_ids, para_fname):
-        """Writes Shot_{pr,vx,vz,ett}{id}.bin; returns None   (fwi_obscalc, Src/Torch_Fwi.cpp:106-136)."""
+    def obscalc(self, Lambda, Mu, Den, Stf, ngpu, Shot_ids, para_fname, to_store=False):
+        """Writes Shot_{pr,vx,vz,ett}{id}.bin; returns None   (fwi_obscalc, Src/Torch_Fwi.cpp:106-136).
+        Extension `to_store=True` (SEPFWI_CALC_OBSERVE_TO_STORE): no files -- the axial-strain gather of every shot goes straight
+        into the HBM store of observed data of the session that will later evaluate that shot (same device, same shot split as
+        `backward` with the same ngpu / ranks), bit for bit what the file route leaves there."""
+        calc = 3 if to_store else 2
         ids = torch.as_tensor(Shot_ids, dtype=torch.int32).cpu()
         n = int(ids.numel())
         if _dist.active():
             lo, hi = _dist.my_block(n)
-            self._cufd(2, self._device_for(Lambda, 0), Lambda, Mu, Den, Stf, ids[lo:hi], para_fname)
+            self._cufd(calc, self._device_for(Lambda, 0), Lambda, Mu, Den, Stf, ids[lo:hi], para_fname)
             _dist.barrier()
             return None
         ngpu = int(ngpu)
         bars = split_shots(n, ngpu)
         if ngpu == 1:
-            self._cufd(2, self._device_for(Lambda, 0), Lambda, Mu, Den, Stf, ids, para_fname)
+            self._cufd(calc, self._device_for(Lambda, 0), Lambda, Mu, Den, Stf, ids, para_fname)
         else:
             with ThreadPoolExecutor(max_workers=ngpu) as ex:
-                futs = [ex.submit(self._cufd, 2, self._device_for(Lambda, i, ngpu), Lambda, Mu, Den, Stf,
+                futs = [ex.submit(self._cufd, calc, self._device_for(Lambda, i, ngpu), Lambda, Mu, Den, Stf,
                                   ids[bars[i]:bars[i + 1]], para_fname) for i in range(ngpu)]
                 [f.result() for f in futs]
         return None

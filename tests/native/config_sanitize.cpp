@@ -37,6 +37,21 @@ int main(int argc, char **argv) {
         printf("FAIL: reference documents mis-parsed\n");
         return 1;
     }
+    {   // "conditioning": "reference": the four keys are parsed (and validated) and then ignored like the reference's driver does; what the
+        // file said about if_win survives for the survey reader, which requires the windows whenever the key is set
+        std::string pr(PARA);
+        pr.insert(pr.rfind('}'), ", \"conditioning\": \"reference\"");
+        Params q = parse_params(pr);
+        if (!q.conditioning_reference || q.if_win || q.has_filter || q.if_src_update || q.if_cross_misfit || !q.if_win_key || q.nz != 96) {
+            printf("FAIL: conditioning = reference mis-parsed\n");
+            return 1;
+        }
+        std::string bad(PARA);
+        bad.insert(bad.rfind('}'), ", \"conditioning\": \"sometimes\"");
+        bool threw = false;
+        try { parse_params(bad); } catch (const std::exception &) { threw = true; }
+        if (!threw) { printf("FAIL: unknown conditioning value accepted\n"); return 1; }
+    }
     // keys that merely start with "shot" are not shots; ids beyond nShots are ignored like the reference's reader does
     // (Src_Rec.cu:78 loops i < group_size over "shot" + to_string(id))
     {

@@ -74,7 +74,8 @@ def _worker(rank, world, port, q):
     zero_copy = (dist.fused_view(m2, gL2, gM2, gD2) is not None and gL2.untyped_storage().data_ptr() == bufs[0].untyped_storage().data_ptr()
                  and ncoll[0] == 1 and torch.equal(gL2, torch.from_numpy(first[3])) and torch.equal(gD2, torch.from_numpy(first[5]))
                  and float(m2) == first[2])
-    q.put(first + (zero_copy,))
+    cs = dist.collective_stats(reset=True)      # two operator calls so far: one staged (separate tensors), one on the buffer itself
+    q.put(first + (zero_copy, cs, dist.collective_stats()))
     td.destroy_process_group()
 
 
@@ -98,6 +99,10 @@ def test_two_ranks_partition_and_single_allreduce():
     for r in res:
         assert r[7] == 1                                    # exactly one collective per operator call
         assert r[9]                                         # fused buffer reduced in place: same storage, same numbers, one collective
+        cs, after = r[10], r[11]                            # the record bench.py prints as "rccl": {...}
+        assert cs["ranks"] == 2 and cs["backend"] == "gloo" and cs["calls"] == 2 and cs["staged"] == 1
+        assert cs["bytes"] == 4 * (3 * 6 * 5 + 1) and cs["allreduce_ms"] is not None and cs["allreduce_ms"] >= 0.0
+        assert after["calls"] == 0 and after["allreduce_ms"] is None
         assert abs(r[2] - (21 + 3.5)) < 1e-5                # misfit summed over ranks
         np.testing.assert_allclose(r[3], eL, rtol=1e-6)
         np.testing.assert_allclose(r[4], eM, rtol=1e-6)

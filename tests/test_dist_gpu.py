@@ -5,6 +5,7 @@ On the one-GPU test box: two gloo ranks sharing the GPU, the single-process `ngp
 one GPU each, against the single-process result with exactly one collective per operator call; the single-process
 `ngpu = 2` path with one session per GPU, fed CPU tensors and tensors resident on GPU 0 (cross-device staging)."""
 import os
+import re
 import socket
 import sys
 
@@ -206,9 +207,33 @@ def test_bench_spawns_its_own_ranks():
         assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
         assert "workload" in line["config"] and "model" not in line["config"]
     assert two["config"]["parallelism"] == "shots x2" and two["value"] > 0
+    # the keys that let the driver verify the collective: how many ranks the backend saw, one all-reduce per step and rank, its size
+    assert "rccl" not in one and one["rank_ms_per_step"]["min"] > 0
+    rc = two["rccl"]
+    assert rc["ranks"] == 2 and rc["backend"] == "gloo" and rc["calls_per_rank"] == 1 and rc["allreduce_ms"] >= 0 and rc["allreduce_ms_max"] >= rc["allreduce_ms"]
+    nzp, nxp = [int(v) for v in re.search(r"padded (\d+)x(\d+)", two["config"]["workload"]).groups()][::-1]
+    assert rc["bytes"] == 4 * (3 * nzp * nxp + 1)
+    assert 0 < two["rank_ms_per_step"]["min"] <= two["rank_ms_per_step"]["max"]
     if torch.cuda.device_count() >= 2:
         rc = _run_bench(["--gpus", "2"])
         assert rc["n_gpus"] == 2 and rc["value"] > 0
+
+
+@pytest.mark.timeout(1100)
+def test_bench_rehearsal_of_the_driver_command_with_four_ranks():
+    """The driver's multi-GPU command shape -- `bench.py --gpus N --steps K --warmup W` on the headline grid -- rehearsed with as
+    many ranks as one card admits: the GPU boxes allow six processes on a device, and this test runner, the launcher and N ranks
+    are N + 2 of them (a six-rank attempt was killed by the box's process guard), so N = 4; the driver's own run has one device
+    per rank.  gloo, all ranks on device 0, 400 time steps.  Every rank models its observed gathers straight into its session's
+    store (no Shot_*.bin files), owns three shots per step, and the line carries the collective's record."""
+    r = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--nz", "1000", "--nx", "2000", "--nsteps", "400",
+                    "--backend", "gloo", "--share-gpu"], timeout=1000)
+    assert r["n_gpus"] == 4 and r["steps"] == 2 and r["warmup"] == 1 and r["value"] > 0 and r["scaling"] == "weak"
+    assert r["config"]["parallelism"] == "shots x4" and r["config"]["shots_per_gpu_per_step"] == 3
+    rc = r["rccl"]
+    assert rc["ranks"] == 4 and rc["backend"] == "gloo" and rc["calls_per_rank"] == 2 and rc["bytes"] == 4 * (3 * 1088 * 2064 + 1)
+    assert rc["allreduce_ms"] > 0 and rc["allreduce_ms_max"] >= rc["allreduce_ms"]
+    assert 0 < r["rank_ms_per_step"]["min"] <= r["rank_ms_per_step"]["max"]
 
 
 def _rccl_one_rank_worker(port, q):

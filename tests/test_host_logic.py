@@ -25,6 +25,17 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert isinstance(L.sepfwi_last_error(), bytes)
 
 
+def test_library_does_not_link_hipfft():
+    """hipFFT is opened with dlopen when the first FFT plan is made (csrc/conditioning.hip FftApi): it is not a DT_NEEDED entry, so
+    a ROCm image without it still loads the propagator; the HIP runtime is the only ROCm library the loader must find."""
+    import subprocess
+    from sepfwi import _native
+    dyn = subprocess.run(["readelf", "-d", _native.LIB_PATH], capture_output=True, text=True, check=True, stdin=subprocess.DEVNULL).stdout
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", dyn)
+    assert any(n.startswith("libamdhip64") for n in needed), needed
+    assert not any("fft" in n.lower() or "rocblas" in n.lower() or "torch" in n.lower() for n in needed), needed
+
+
 def test_no_gpu_is_a_loud_error_not_a_fallback(tmp_path):
     """On a box without a HIP device the operator must raise (never compute on the CPU)."""
     if torch.cuda.is_available():
