@@ -34,6 +34,10 @@ class Conditioner {
     // transpose of the map syn -> updated syn at the coefficients of the last source_update: pad, FFT, conj(coef), inverse FFT,
     // end taper of the padded length, crop.  (Conscious fix of source_update_adj, utilities.cu:1283-1325: oracle/oracle.py.)
     void source_update_adj(hipStream_t st, float *res, int nrec, float dt);
+    // the second padded gather / spectrum and the coefficients of the source update, allocated (and the coefficients zeroed on `st`)
+    // once; the session calls it up-front when the parameter file sets if_src_update, so that device_bytes() is complete and no
+    // shot pays an allocation inside its time loop
+    void ensure_source_buffers(hipStream_t st);
     long long device_bytes() const;
 
   private:
@@ -41,7 +45,6 @@ class Conditioner {
         void *fwd, *inv;  // hipfftHandle
     };
     Plans &plans_for(int nrec, hipStream_t st);
-    void ensure_source_buffers(hipStream_t st);
     int nt_, cap_;
     float *pad_ = nullptr, *norm_ = nullptr, *pad2_ = nullptr;
     void *spec_ = nullptr;  // hipfftComplex [cap][nt + 1]

@@ -203,6 +203,7 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     if (cond_on_) {
         xpose2_ = dalloc<float>(dlen);
         cond_.reset(new Conditioner(par.nSteps, std::max(1, survey_.max_nrec)));
+        if (par.if_src_update) cond_->ensure_source_buffers(own_stream_);  // now, so that sepfwi_stats.device_bytes counts them
         device_bytes_ += cond_->device_bytes();
     }
     HIP_OK(hipHostMalloc((void **)&h_io_, dlen * sizeof(float), hipHostMallocDefault));
@@ -370,11 +371,27 @@ long long Session::pack_offset(int shot_id, int nrec) {
             fclose(fp);
             throw IoError("packed observed data '" + par_.obs_pack_fname + "' was written for another nSteps");
         }
+        const long long head_bytes = 16 + 16LL * head[0];  // magic + (count, nSteps) + count x (id, nrec, offset)
+        std::string bad;
         for (int k = 0; ok && k < head[0]; k++) {
             int32_t e[2];
             int64_t off;
             ok = fread(e, 4, 2, fp) == 2 && fread(&off, 8, 1, fp) == 1;
-            if (ok) pack_index_[e[0]] = std::make_pair((long long)off, (int)e[1]);
+            if (!ok) break;
+            // every entry is checked where it is read: a corrupt index must not look like "shot not in the pack" (silent fall-back to
+            // Shot_ett{id}.bin) or surface later as a short read on some other file
+            const long long want = (long long)e[1] * (long long)par_.nSteps * (long long)sizeof(float);
+            if (e[1] < 0 || off < head_bytes || off > (long long)sb.st_size || want > (long long)sb.st_size - off)
+                bad = "entry " + std::to_string(k) + " (shot " + std::to_string(e[0]) + ") points outside the file";
+            else if (pack_index_.count(e[0]))
+                bad = "shot " + std::to_string(e[0]) + " is listed twice";
+            if (!bad.empty()) break;
+            pack_index_[e[0]] = std::make_pair((long long)off, (int)e[1]);
+        }
+        if (!bad.empty()) {
+            fclose(fp);
+            pack_index_.clear();
+            throw IoError("packed observed data '" + par_.obs_pack_fname + "': " + bad);
         }
         fclose(fp);
         if (!ok) throw IoError("'" + par_.obs_pack_fname + "' is not a packed observed-data file");

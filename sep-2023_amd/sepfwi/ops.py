@@ -90,7 +90,9 @@ class _FwiOps:
         # gradients are allocated where the session writes them in place: on ITS GPU when the model lives on a GPU
         # (also another one: single-process ngpu > 1), on the host for the reference's CPU tensors
         gdev = torch.device("cuda", gpu_id) if Lambda.is_cuda else torch.device("cpu")
-        misfit = torch.zeros(1, dtype=torch.float32)
+        # the loss lives where the model lives (the reference: CPU tensors throughout, torch::zeros(1)); calc_id 1 below makes it the
+        # last element of the gradient buffer
+        misfit = torch.zeros(1, dtype=torch.float32, device=gdev if calc_id == 0 else "cpu")
         gL = gM = gD = gS = None
         if calc_id == 1:
             # ONE buffer [gLambda | gMu | gDen | misfit]: the session writes all four in place, and under torch.distributed
@@ -152,6 +154,7 @@ class _FwiOps:
                                   ids[bars[i]:bars[i + 1]], para_fname, Lambda.device) for i in range(ngpu)]
                 parts = [f.result() for f in futs]
         m, gL, gM, gD, gS0 = parts[0]
+        m = m.clone()                    # not a view of the fused [gL | gM | gD | misfit] buffer: a kept loss must not pin 3 nz nx floats
         for p in parts[1:]:              # sum of Torch_Fwi.cpp:96-101 (every part already sits on Lambda's device)
             m = m + p[0]
             gL += p[1]

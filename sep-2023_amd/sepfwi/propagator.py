@@ -9,7 +9,10 @@ of FWI_ops.py:124-125 (propagator.py:103-104): the operator works in MPa, so thi
 kg/m^3 -- kept as the reference has it.
 
 What is different: `device=` (a HIP device) keeps the padded moduli, the gradients and the chain rule in HBM; the default
-(None) hands CPU tensors over as the reference does.  The numpy results are the same either way."""
+(None) hands CPU tensors over as the reference does.  The two routes differ in the last step only: the default multiplies the
+operator's float32 gradients by the caller's numpy model arrays (float64 unless the caller made them float32), as the reference
+does, and returns that dtype; with `device=` the chain rule runs in float32 on the GPU and float32 arrays come back -- the same
+numbers to about 1e-7 relative."""
 from __future__ import annotations
 
 import os
