@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--pert", type=float, default=0.1, help="amplitude of the true model's random perturbation (bench.marmousi_style: 0.1)")
     ap.add_argument("--sigma-init", type=float, default=40.0, help="Gaussian smoothing [cells] that makes the initial model from the true one (40)")
     ap.add_argument("--step0", type=float, default=20.0, help="largest model change [m/s, kg/m^3] of L-BFGS-B's first trial step (objective scaling)")
+    ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after the iteration that ends beyond this many seconds (0: no limit)")
     ap.add_argument("--files", action="store_true", help="observed data through Shot_*.bin files as the reference does (default: straight into the HBM store)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend under torchrun (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0: rehearsal of the N-rank run on a one-GPU box (with --backend gloo)")
@@ -154,7 +155,9 @@ def main():
     def cb(x):
         hist.append(obj.f)
         if rank == 0:
-            print("iterate %d: misfit %.6e   elapsed %.1f s" % (len(hist) - 1, obj.f, time.perf_counter() - t0), flush=True)
+            print("iterate %d: misfit %.6e   elapsed %.1f s   (%d gradient evaluations so far)" % (len(hist) - 1, obj.f, time.perf_counter() - t0, len(evals)), flush=True)
+        if a.max_seconds > 0 and time.perf_counter() - t0 > a.max_seconds:
+            raise StopIteration
 
     lb_opts = {"gtol": 1e-16, "maxiter": a.niter, "ftol": 1e-12, "maxcor": 5, "maxfun": 1500, "maxls": 6}
     if a.scipy_minimize:

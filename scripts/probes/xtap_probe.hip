@@ -11,6 +11,9 @@
 //              x-taps mostly from the lane's own registers, 1-2 halo values per lane and array by (cached) loads
 //   variant 4: LDS halo staging of the z-direction: blocks of 8 rows stage their rows of szz / sxz (+ 5 halo rows) in LDS
 //              once, one barrier, every z-tap is an LDS read (the x-taps stay shifted loads)
+//   variants 5, 6 (round 4): REGISTER TILING IN Z -- a wave owns R = 2 / 4 consecutive rows of its 64 columns, so the z-taps of
+//              neighbouring rows are loaded once (szz: R + 3 loads instead of 4 R; sxz: R + 3 + 3 R instead of 7 R): 17 % / 26 % fewer
+//              loads per cell at R / 2 ... R / 4 of the waves
 // Prints microseconds per launch (mean of the back half of 400 launches) and the checksum of the result (equal for all).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o xtap_probe xtap_probe.hip && ./xtap_probe
 #include <hip/hip_runtime.h>
@@ -171,6 +174,52 @@ __global__ __launch_bounds__(512) void k_update_lds(const float *__restrict__ sz
     vx[i] = vx0 + (dsxz_dz + dsxx_dx) * bb * 1e-3f;
 }
 
+// variants 5, 6: R rows per wave, z-taps shared in registers
+template <int R>
+__global__ __launch_bounds__(1024) void k_update_rows(const float *__restrict__ szz, const float *__restrict__ sxz, const float *__restrict__ sxx,
+                                                      const float *__restrict__ rho, float *__restrict__ vz, float *__restrict__ vx, int gx, int gyR) {
+    int t = blockIdx.x;
+    const int per = (gx * gyR + 7) >> 3;
+    t = (t & 7) * per + (t >> 3);
+    const int ty = t / gx, tx = t - ty * gx;
+    if (ty >= gyR) return;
+    const int x = tx * 64 + (threadIdx.x & 63);
+    const int z0 = __builtin_amdgcn_readfirstlane((ty * 2 + (int)(threadIdx.x >> 6)) * R);
+    if (z0 > NZ - 3) return;
+    auto row = [&](const float *a, int zz, int dx) { return (zz >= 0 && zz < NZ + 4 && x + dx >= 0 && x + dx < P) ? a[(size_t)zz * P + x + dx] : 0.0f; };
+    float zz[R + 3], xz[R + 3], rr[R + 1];
+#pragma unroll
+    for (int k = 0; k < R + 3; k++) {
+        zz[k] = row(szz, z0 - 1 + k, 0);   // rows z0-1 .. z0+R+1
+        xz[k] = row(sxz, z0 - 2 + k, 0);   // rows z0-2 .. z0+R
+    }
+#pragma unroll
+    for (int k = 0; k < R + 1; k++) rr[k] = row(rho, z0 + k, 0);
+    float xzm2[R], xzm1[R], xzp1[R], xxm1[R], xx0[R], xxp1[R], xxp2[R], rx[R], ovz[R], ovx[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int z = z0 + r;
+        xzm2[r] = row(sxz, z, -2); xzm1[r] = row(sxz, z, -1); xzp1[r] = row(sxz, z, 1);
+        xxm1[r] = row(sxx, z, -1); xx0[r] = row(sxx, z, 0); xxp1[r] = row(sxx, z, 1); xxp2[r] = row(sxx, z, 2);
+        rx[r] = row(rho, z, 1);
+        ovz[r] = row(vz, z, 0); ovx[r] = row(vx, z, 0);
+    }
+    if (x < 2 || x > NX - 3) return;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int z = z0 + r;
+        if (z < 2 || z > NZ - 3) continue;
+        const size_t i = (size_t)z * P + x;
+        const float dszz_dz = dplus(zz[r], zz[r + 1], zz[r + 2], zz[r + 3]);
+        const float dsxz_dz = dminus(xz[r], xz[r + 1], xz[r + 2], xz[r + 3]);
+        const float dsxz_dx = dminus(xzm2[r], xzm1[r], xz[r + 2], xzp1[r]);
+        const float dsxx_dx = dplus(xxm1[r], xx0[r], xxp1[r], xxp2[r]);
+        const float ba = 2.0f / (rr[r + 1] + rr[r]), bb = 2.0f / (rx[r] + rr[r]);
+        vz[i] = ovz[r] + (dszz_dz + dsxz_dx) * ba * 1e-3f;
+        vx[i] = ovx[r] + (dsxz_dz + dsxx_dx) * bb * 1e-3f;
+    }
+}
+
 int main() {
     const size_t n = (size_t)(NZ + 4) * P;
     float *d[6];
@@ -191,7 +240,9 @@ int main() {
     OK(hipEventCreate(&e1));
     const int gx4 = (NX + 255) / 256, nb4 = ((gx4 * gy + 7) / 8) * 8;
     const int gy8 = (NZ + 7) / 8, nb8 = ((gx * gy8 + 7) / 8) * 8;
-    for (int var = 0; var < 5; var++) {
+    const int gyR2 = (NZ + 3) / 4, nbR2 = ((gx * gyR2 + 7) / 8) * 8;      // 2 waves x 2 rows per block
+    const int gyR4 = (NZ + 7) / 8, nbR4 = ((gx * gyR4 + 7) / 8) * 8;      // 2 waves x 4 rows per block
+    for (int var = 0; var < 7; var++) {
         for (int k = 4; k < 6; k++) OK(hipMemset(d[k], 0, n * sizeof(float)));
         float ms = 0;
         for (int rep = 0; rep < 400; rep++) {
@@ -201,6 +252,8 @@ int main() {
             if (var == 2) hipLaunchKernelGGL(k_update<2>, dim3(nb), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy);
             if (var == 3) hipLaunchKernelGGL(k_update4, dim3(nb4), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx4, gy);
             if (var == 4) hipLaunchKernelGGL(k_update_lds, dim3(nb8), dim3(512), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gy8);
+            if (var == 5) hipLaunchKernelGGL(k_update_rows<2>, dim3(nbR2), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gyR2);
+            if (var == 6) hipLaunchKernelGGL(k_update_rows<4>, dim3(nbR4), dim3(128), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], gx, gyR4);
         }
         OK(hipEventRecord(e1, 0));
         OK(hipEventSynchronize(e1));
@@ -211,7 +264,7 @@ int main() {
         OK(hipMemcpy(h.data(), d[5], n * sizeof(float), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) cs += 3.0 * h[i];
         printf("variant %d (%s): %.2f us per launch, checksum %.9e\n", var,
-               var == 0 ? "all taps global loads" : var == 1 ? "x-taps by ds_bpermute" : var == 2 ? "x-taps by DPP wave shifts" : var == 3 ? "four columns per lane, 16-byte loads" : "z-taps staged in LDS, 8-row blocks", 1e3 * ms / 200.0, cs);
+               var == 0 ? "all taps global loads" : var == 1 ? "x-taps by ds_bpermute" : var == 2 ? "x-taps by DPP wave shifts" : var == 3 ? "four columns per lane, 16-byte loads" : var == 4 ? "z-taps staged in LDS, 8-row blocks" : var == 5 ? "two rows per wave, z-taps shared in registers" : "four rows per wave, z-taps shared in registers", 1e3 * ms / 200.0, cs);
     }
     return 0;
 }
