@@ -10,7 +10,10 @@ tail -15 gpurun_out/r04_fuzz_$A.log
 python - <<'PY'
 import numpy as np
 a = np.loadtxt("gpurun_out/r04_fuzz_yard.txt", ndmin=2)
+big = a[:, 1] > 3.3e-4
 print("%d draws; oracle vs its nvcc-FMA build, worst gradient rel-L2: median %.1e, 90 %% %.1e, 99 %% %.1e, max %.1e; draws where it exceeds 3.3e-4 (the yardstick, not the nominal 1e-3, decides): %d"
-      % (len(a), np.median(a[:, 1]), np.quantile(a[:, 1], .9), np.quantile(a[:, 1], .99), a[:, 1].max(), int((a[:, 1] > 3.3e-4).sum())))
+      % (len(a), np.median(a[:, 1]), np.quantile(a[:, 1], .9), np.quantile(a[:, 1], .99), a[:, 1].max(), int(big.sum())))
+print("records lengthened x2: %d, x4: %d; of the yardstick-decided draws: %d with a water layer, by extension 0..5: %s"
+      % (int((a[:, 3] == 2).sum()), int((a[:, 3] == 4).sum()), int((big & (a[:, 4] > 0)).sum()), [int((big & (a[:, 5] == k)).sum()) for k in range(6)]))
 PY
 exit $rc
