@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--step0", type=float, default=20.0, help="largest model change [m/s, kg/m^3] of L-BFGS-B's first trial step (objective scaling)")
     ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after the iteration that ends beyond this many seconds (0: no limit)")
     ap.add_argument("--no-restart", action="store_true", help="end at the first line-search failure like the reference's scripts instead of restarting L-BFGS-B from the current iterate")
+    ap.add_argument("--mask-rows", type=int, default=4, help="rows below the surface kept fixed (the reference's scripts: 4; sources and fibre sit in row 2)")
     ap.add_argument("--files", action="store_true", help="observed data through Shot_*.bin files as the reference does (default: straight into the HBM store)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend under torchrun (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0: rehearsal of the N-rank run on a one-GPU box (with --backend gloo)")
@@ -119,7 +120,7 @@ def main():
     t_obs = time.perf_counter() - t0
 
     Mask = torch.zeros((pb["nz_pad"], pb["nx_pad"]), dtype=torch.float32, device=dev)
-    Mask[nPml + 4:nPml + a.nz, nPml:nPml + a.nx] = 1.0     # keep the source / fibre rows fixed (Main-001-...py:62-66)
+    Mask[nPml + a.mask_rows:nPml + a.nz, nPml:nPml + a.nx] = 1.0     # keep the source / fibre rows fixed (Main-001-...py:62-66: 4 rows)
     T = lambda m: torch.tensor(m, dtype=torch.float32, device=dev, requires_grad=True)
     box = lambda m: (np.full(m.shape, float(m.min()) * 0.8), np.full(m.shape, float(m.max()) * 1.2))   # all three or none
     if a.no_bounds:

@@ -258,8 +258,11 @@ def _rccl_one_rank_worker(port, q):
     view = dist.fused_view(m, gL, gM, gD)
     m2, a, b, c = dist.allreduce_gradients(m, gL, gM, gD)
     torch.cuda.synchronize()
+    cs = dist.collective_stats(reset=True)      # the record bench.py prints as "rccl": HIP-event pair around the collective, no staging
     ok = (view is not None and view.data_ptr() == fused.data_ptr() and ncoll[0] == 1 and torch.equal(fused, want)
-          and a.data_ptr() == gL.data_ptr() and m2.data_ptr() == m.data_ptr() and td.get_backend() == "nccl")
+          and a.data_ptr() == gL.data_ptr() and m2.data_ptr() == m.data_ptr() and td.get_backend() == "nccl"
+          and cs["backend"] == "nccl" and cs["ranks"] == 1 and cs["calls"] == 1 and cs["staged"] == 0 and cs["bytes"] == 4 * (3 * n + 1)
+          and cs["allreduce_ms"] is not None and cs["allreduce_ms"] > 0.0)
     q.put(bool(ok))
     td.destroy_process_group()
 

@@ -481,3 +481,23 @@ def test_header_is_valid_c_and_cpp(tmp_path):
                    '        throw std::runtime_error(sepfwi_last_error());\n'
                    '    return misfit;\n}\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)])
+
+
+def test_collective_record_without_a_process_group():
+    """dist.collective_stats() outside torch.distributed: one rank, no backend, nothing counted (bench.py prints "rccl" only for N > 1)."""
+    from sepfwi import dist
+    cs = dist.collective_stats(reset=True)
+    assert cs["ranks"] == 1 and cs["backend"] is None and cs["calls"] == 0 and cs["allreduce_ms"] is None and cs["staged"] == 0
+
+
+def test_paragen_writes_the_conditioning_switch_only_when_asked(tmp_path):
+    """Default parameter files stay byte-identical to the reference's schema; "conditioning" appears only when given, and only the two
+    legal values are accepted."""
+    from sepfwi import utils as ft
+    a, b = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 4, a, "s.json", str(tmp_path / "D"))
+    ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 4, b, "s.json", str(tmp_path / "D"), filter_para=[1, 2, 3, 4], conditioning="reference")
+    ja, jb = json.load(open(a)), json.load(open(b))
+    assert "conditioning" not in ja and jb["conditioning"] == "reference" and jb["filter"] == [1, 2, 3, 4]
+    with pytest.raises(ValueError):
+        ft.paraGen(96, 80, 10.0, 10.0, 100, 1e-3, 10.0, 10, 4, a, "s.json", str(tmp_path / "D"), conditioning="sometimes")
