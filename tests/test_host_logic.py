@@ -108,6 +108,12 @@ def test_json_errors_are_reported_not_fatal(tmp_path):
     rc = L.sepfwi_cufd(None, None, None, None, None, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 7, 0, 1,
                        ids.ctypes.data, str(bad).encode())
     assert rc == -1 and b"calc_id" in L.sepfwi_last_error()
+    # calc_id 3 (SEPFWI_CALC_OBSERVE_TO_STORE, the one value beyond the reference's 0 / 1 / 2) is accepted: the call gets as far as the file
+    rc = L.sepfwi_cufd(None, None, None, None, None, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 3, 0, 1,
+                       ids.ctypes.data, str(bad).encode())
+    assert rc == -5
+    hdr = open(os.path.join(ROOT, "include", "sepfwi.h")).read()
+    assert "#define SEPFWI_CALC_OBSERVE_TO_STORE 3" in hdr and "#define SEPFWI_CALC_OBSERVE 2" in hdr
 
 
 def test_para_and_survey_writers_schema(tmp_path):
