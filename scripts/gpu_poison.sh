@@ -5,10 +5,10 @@
 #   usage: gpu_poison.sh [fuzz seeds, default 600]
 mkdir -p gpurun_out
 export SEPFWI_POISON=1
-( time timeout -k 10 1100 python -m pytest tests -m gpu -q ) > gpurun_out/poison_suite.log 2>&1
+( time timeout -k 10 800 python -m pytest tests -m gpu -q ) > gpurun_out/poison_suite.log 2>&1
 grep "passed\|failed" gpurun_out/poison_suite.log | tail -1
 export SEPFWI_FUZZ_N=${1:-600} OMP_NUM_THREADS=2
-( time timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -n 6 ) > gpurun_out/poison_fuzz.log 2>&1
+( time timeout -k 10 300 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -n 4 ) > gpurun_out/poison_fuzz.log 2>&1
 grep "passed\|failed" gpurun_out/poison_fuzz.log | tail -1
 grep -h "^E   *AssertionError\|^FAILED\|crashed" gpurun_out/poison_suite.log gpurun_out/poison_fuzz.log | cut -c1-220 | head -30
 exit 0
