@@ -289,6 +289,7 @@ def main():
             fwd_ms += st["fwd_ms"]
             bwd_ms += st["bwd_ms"]
             call_ms += st["total_ms"]       # this rank's own propagator call, without the collective and its wait for the slowest rank
+            n_launch = st["launches"]       # kernel launches of the last call (every shot, both time loops, set-up and finalisation)
             probe_us += st["probe_kernel_us"] * st["probe_calls"]
             probe_n += st["probe_calls"]
         torch.cuda.synchronize()
@@ -357,6 +358,10 @@ def main():
                              "bwd_step_frac": round(pb["n_c"] * 124.0 / (bwd_ms * 1e3 / nst * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if bwd_ms > 0 else None},
                 "fwd_ms_per_shot": round(fwd_ms / (K * spr), 2), "bwd_ms_per_shot": round(bwd_ms / (K * spr), 2),
                 "fwd_us_per_time_step": round(fwd_ms * 1e3 / nst, 2), "bwd_us_per_time_step": round(bwd_ms * 1e3 / nst, 2),
+                # SURVEY.md 8(d) "what else to report": device time of the two time loops (HIP events) beside the wall time of a step,
+                # and launches per shot and time step (the reference: 12 forward + 12 backward; here 2 + 2 on a line of channels)
+                "device_ms_per_step": round((fwd_ms + bwd_ms) / max(K, 1), 3),
+                "launches_per_shot_time_step": round(n_launch / float(spr * (args.nsteps - 1)), 3),
             }
             # did the collective backend really see N ranks, and what did the one all-reduce per step cost?  `allreduce_ms` is the mean
             # HIP-event time around the collective on the rank that waited least (the last to arrive: the collective itself); `_max`
