@@ -26,7 +26,7 @@ class AltOps:
 import test_gpu_fuzz as T
 for seed in T._SEEDS:
     try:
-        T.test_random_problem_matches_oracle(pathlib.Path(tempfile.mkdtemp()), O, AltOps(), seed)
+        T.test_random_problem_matches_oracle(pathlib.Path(tempfile.mkdtemp()), O, O.load_variant("nvfma"), AltOps(), seed)
         print("seed", seed, "passed")
     except AssertionError as e:
         print("seed", seed, "ASSERT", str(e)[:200])
