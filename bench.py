@@ -77,6 +77,31 @@ def setup_problem(workdir, nz, nx, nSteps, n_shots_total, nPml=32, dh=10.0, dt=1
                 nz_pad=nz_pad, nx_pad=nx_pad, n_c=(nz + 2 * nPml) * nx_pad, nrec=int(rec_x.size))
 
 
+def effective_cores():
+    """Host cores this process may really use: the smaller of the scheduler affinity and the cgroup CPU quota (a GPU box shows its
+    host's 256 hardware threads in os.cpu_count() but may grant a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(nz, nx, seconds=12.0):
     """The reference's CPU propagator is the Numba solver (DAS_Waveform_Modeling/src/elasticSolver.py);
     numba cannot travel, so its C restatement (oracle/numba_oracle.c, pinned bit-for-bit to the reference
@@ -88,7 +113,7 @@ def cpu_baseline(nz, nx, seconds=12.0):
     from oracle import oracle as O
     O.build()
     host_cores = os.cpu_count() or 1
-    cores = max(1, min(host_cores, 32))
+    cores = max(1, min(effective_cores(), 32))
     ndamp = 32
     vp = np.full((nx, nz), 3000.0)
     vs = vp / 1.732
@@ -114,7 +139,7 @@ def cpu_baseline(nz, nx, seconds=12.0):
     val = cores * cells * nt / el / 1e9
     out = {"value": round(val, 5), "unit": "Gcell-updates/s", "cores": cores, "kind": "port",
            "sample": "float64 C restatement of elasticSolver.py (velocity+stress = 1 cell-update), %dx%d grid + %d sponge, "
-                     "%d steps, %d shots in parallel (one per core; os.cpu_count() = %d, capped at 32), forward only, %.1f s"
+                     "%d steps, %d shots in parallel (one per core: the smaller of scheduler affinity, cgroup quota and 32; os.cpu_count() = %d), forward only, %.1f s"
                      % (nx, nz, ndamp, nt, cores, host_cores, el),
            "one_core": {"value": round(one_core, 5), "unit": "Gcell-updates/s", "cores": 1,
                         "sample": "the same solver, one shot on one core, %d steps, %.1f s" % (nt1, t_one)}}
@@ -157,6 +182,11 @@ def cpu_baseline_fwdadj(nz, nx, cores, seconds):
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
+    try:    # one OpenMP thread per shot: libgomp would otherwise start one per hardware thread of the HOST (256) and let the idle ones spin
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(cores))
+    except OSError:
+        pass
     # Differential timing: allocation, the model averages, file set-up and the thread start-up are the same for a short and a
     # long run, so the rate is (work of the extra time steps) / (extra time); the long run is repeated and both figures are
     # reported (the hosts are shared: the spread between two identical runs is part of the answer).
