@@ -309,6 +309,7 @@ def main():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
+        _dist.enable_collective_timing(True)
         _dist.collective_stats(reset=True)
         t0 = time.perf_counter()
         fwd_ms = bwd_ms = call_ms = 0.0

@@ -32,6 +32,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as td
     td.init_process_group("gloo", rank=rank, world_size=world)
     from sepfwi import dist
+    dist.enable_collective_timing(True)
     from sepfwi.ops import fwi_ops
     seen = []
     ncoll = [0]

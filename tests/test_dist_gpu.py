@@ -243,6 +243,7 @@ def _rccl_one_rank_worker(port, q):
     torch.cuda.set_device(0)
     td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from sepfwi import dist
+    dist.enable_collective_timing(True)
     n, shape = 37 * 53, (37, 53)
     fused = torch.arange(3 * n + 1, dtype=torch.float32, device="cuda") * 0.5
     want = fused.clone()
