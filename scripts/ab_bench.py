@@ -18,7 +18,7 @@ from sepfwi import _native, fwi_ops
 
 
 DEFAULTS = dict(bz=2, xcd_remap=1, bwd_fuse=2, line_fuse=1, pair_fwd=1, fwd_lanes=3, early=0, rho_fly=1, amu_fly=1, rk_lazy=1, batch=2, batch_f=0,
-                batch_b=0, batch_mb=200, batch_order=1, img_every=1)
+                batch_b=0, batch_mb=200, batch_order=1, img_every=1, pk_lmask=7, pk_wpc=1, pk_waves=16, pk_px=0, pk_chunk=0, pk_flags=0)
 
 
 def main():
@@ -50,7 +50,12 @@ def main():
                         continue
                     k, val = kv.split("=")
                     _native.check(L.sepfwi_set_option(k.encode(), int(val)))
-                out = fwi_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+                try:
+                    out = fwi_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+                except RuntimeError as e:   # e.g. a persistent grid that cannot be resident
+                    if r == 0:
+                        print("variant %s failed: %s" % (v, str(e)[:200]))
+                    continue
                 st = fwi_ops.stats(pb["para_fname"], 0)
                 if r > 0:
                     res[v].append((st["fwd_ms"] * 1e3 / st["fwd_steps"], st["bwd_ms"] * 1e3 / st["bwd_steps"]))
@@ -62,6 +67,8 @@ def main():
                     print("WARNING variant %s result deviates from first variant by %.2e" % (v, dev_))
         nc = pb["n_c"]
         for v in a.variants:
+            if not res[v]:
+                continue
             f = np.array([x[0] for x in res[v]]); b = np.array([x[1] for x in res[v]])
             tot = np.median(f) + np.median(b)
             print("%-40s fwd %7.2f us (min %7.2f)  bwd %7.2f us (min %7.2f)  -> %6.2f Gcell-updates/s" %

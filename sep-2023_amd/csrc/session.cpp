@@ -120,6 +120,10 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     grad_stage_ = dalloc<float>(3 * dense);
     scal_ = dalloc<double>(4);
     cp2_bits_ = dalloc<unsigned int>(4);
+    persist_args_ = dalloc<PersistArgs>(kPersistSlots);
+    persist_flags_ = dalloc<unsigned int>(kPersistFlags);
+    persist_stf_ = dalloc<float>((size_t)par.nSteps);
+    HIP_OK(hipMemset(persist_flags_, 0, kPersistFlags * sizeof(unsigned int)));
 
     // ---- C-PML profiles (host) -> device, with 1/K precomputed ----
     {
@@ -809,7 +813,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         Grid gs = g;  // this step's imaging weight (option img_every)
         if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-        if (fuse_bwd == 2) {
+        if (fuse_bwd == 2 || fuse_bwd == 4) {
             launch_bwd_a(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
             launch_bwd_b(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
             if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
@@ -832,11 +836,64 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         n_probe = 0;
     };
+    // the whole backward pass of one shot as persistent launches (option bwd_fuse = 4; kernels.hip k_bwd_persist)
+    auto backward_persistent = [&](const ShotCtx &c, const BwdLane &L) {
+        int dev_cus = 0;
+        HIP_OK(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, gpu_id_));
+        const int nband = 8, threads = 64 * opt.pk_waves;
+        const int nwg = (dev_cus / nband) * nband * opt.pk_wpc;
+        PersistArgs a{};
+        int max_seg = 0;
+        persist_geometry(g, nwg, nband, opt.pk_px, &a, &max_seg);
+        int nl = 0;
+        for (int k = 0; k < 5; k++) nl += (opt.pk_lmask >> k) & 1;
+        a.tile_cap = max_seg;
+        const size_t lds_bytes = (size_t)nl * (size_t)max_seg * 64 * sizeof(float);
+        ShotDev &d = a.s;
+        d.fields = c.state;
+        d.frame = c.frame;
+        d.stf = persist_stf_;
+        d.bmem = L.bm.dvz_dz;
+        d.adj = L.adj.vz;
+        d.acc = L.acc.lam;
+        d.res = c.res;
+        d.stf_grad = stf_grad_ + (size_t)c.is * nSteps;
+        d.z_src = c.sh->z_src;
+        d.x_src = c.sh->x_src;
+        d.lr_z = c.line.z;
+        d.lr_x0 = c.line.x0;
+        d.lr_n = c.line.n;
+        d.nrec = c.nrec;
+        d.src_rxz = (float)c.sh->src_rxz;
+        a.media = md_.lam;
+        a.cz = pc_.a_z;
+        a.n = n;
+        a.src_scale = src_scale;
+        a.img_every = opt.img_every;
+        a.flags = persist_flags_;
+        a.err = (int *)(persist_flags_ + kPersistFlags - 1);
+        HIP_OK(hipMemcpyAsync(persist_stf_, c.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, L.s));
+        const int chunk = opt.pk_chunk > 0 ? opt.pk_chunk : nSteps;
+        int slot = 0;
+        for (int hi = nSteps - 2; hi >= 0; hi -= chunk, slot++) {
+            a.it_hi = hi;
+            a.it_lo = std::max(0, hi - chunk + 1);
+            if (slot >= kPersistSlots) throw std::invalid_argument("pk_chunk: too many launches per pass");
+            HIP_OK(hipMemcpyAsync(persist_args_ + slot, &a, sizeof(a), hipMemcpyHostToDevice, L.s));
+            HIP_OK(hipStreamSynchronize(L.s));  // `a` is pageable host memory
+            const int rc = launch_bwd_persist(L.s, g, opt, persist_args_ + slot, nwg, threads, opt.pk_lmask, lds_bytes);
+            if (rc != 0) throw HipError("persistent backward loop cannot be launched (code " + std::to_string(rc) + "): grid not resident or LDS too small");
+            launches_++;
+        }
+    };
     auto backward = [&](const ShotCtx &c) {
         const BwdLane L{st, mem_, adj_, acc_};
         HIP_OK(hipEventRecord(ev_[2], st));
         backward_init(L);
-        for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
+        if (fuse_bwd == 4 && (c.nrec == 0 || (c.line.n > 0 && opt.line_fuse != 0)))
+            backward_persistent(c, L);
+        else
+            for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
         HIP_OK(hipEventRecord(ev_[3], st));
         bwd_steps_ += (long long)(nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));
