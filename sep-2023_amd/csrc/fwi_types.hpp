@@ -112,8 +112,10 @@ struct PersistArgs {
     int it_hi, it_lo;
     float src_scale;
     int img_every;
-    int nband, px, pz;  // tiles: nband row bands (one per XCD) x pz x px
-    int tile_cap;       // row segments per LDS-resident accumulator array
+    int nband, per_band;  // tiles: nband row bands (one per XCD) x per_band tiles
+    int cap;              // slots per tile in `seg`, and row segments per LDS-resident accumulator array
+    const uint32_t *seg;  // [tiles][cap] segment descriptors (persist_plan.hpp)
+    const struct TileHdr *hdr;
     unsigned int *flags;  // per tile: phases completed
     int *err;
 };

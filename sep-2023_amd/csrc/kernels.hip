@@ -32,6 +32,7 @@
 
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -728,29 +729,14 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
 
 // ---------------------------------------------------------------------------------------------
 // Persistent backward time loop (option bwd_fuse = 4): ONE launch advances a shot through many backward time steps.
-// The grid is occupancy-sized (every workgroup resident at once); a workgroup owns a fixed rectangular tile of
+// The grid is occupancy-sized (every workgroup resident at once); a workgroup owns a fixed tile of
 // 64-column row segments for the whole launch and walks it twice per time step: phase A = the k_bwd_a bodies,
 // phase B = the k_bwd_b bodies (same bodies, same order of operations on every array: Src/libCUFD.cu:545-631).
 // Fixed ownership is what the per-step launches cannot have: the imaging accumulators of the tile never leave
 // the CU (LDS; template mask LMASK), and there is no grid fill / drain between the 2 x 3999 phases of a pass.
-// Tiles: `nband` row bands (band = blockIdx % nband: the blocks of one XCD under round-robin dispatch), each
-// cut into pz x px tiles; a tile is [z0,z1) x segments [s0,s1).
+// Tiles come from a host-built plan (persist_plan.hpp): per workgroup a list of row segments (edge segments first), every
+// tile the same size +- 1; band = blockIdx % nband is the XCD under round-robin dispatch.
 // ---------------------------------------------------------------------------------------------
-struct TileGeom {
-    int z0, z1, s0, s1;
-};
-__device__ __forceinline__ TileGeom tile_of(const Grid &g, const PersistArgs &a, int bid) {
-    const int band = bid % a.nband, slot = bid / a.nband;
-    const int tzi = slot / a.px, txi = slot - tzi * a.px;
-    const int rb0 = (int)((long long)g.nzc * band / a.nband), rb1 = (int)((long long)g.nzc * (band + 1) / a.nband);
-    TileGeom t;
-    t.z0 = rb0 + (rb1 - rb0) * tzi / a.pz;
-    t.z1 = rb0 + (rb1 - rb0) * (tzi + 1) / a.pz;
-    t.s0 = g.gx * txi / a.px;
-    t.s1 = g.gx * (txi + 1) / a.px;
-    return t;
-}
-
 // FLAGS (probe): 1 segments handed out wave by wave from an LDS counter instead of a fixed stride, 2 no workgroup barrier
 // between phases (timing only), 4 registers capped for 8 waves per SIMD
 template <int LMASK, int FLAGS>
@@ -765,18 +751,20 @@ __global__ __launch_bounds__(MAXT, (FLAGS & 4) ? 8 : 4) void k_bwd_persist(Grid 
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(a.media, n);
     const PmlCoef pc = coef_of(a.cz, a.cz + 6 * g.nzc, g.nzc, g.nx);
-    const TileGeom t = tile_of(g, a, blockIdx.x);
-    const int tw = t.s1 - t.s0, nst = tw * (t.z1 - t.z0);
+    const int tile = (int)(blockIdx.x % a.nband) * a.per_band + (int)(blockIdx.x / a.nband);
+    const TileHdr &h = a.hdr[tile];
+    const uint32_t *__restrict__ segs = a.seg + (size_t)tile * (size_t)a.cap;
+    const int nst = h.n_seg;
     const int lane = threadIdx.x & (BX - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
     lds_float *const lbase = (lds_float *)lds_dyn;
-    AccT<LMASK> acc{acc_of(s.acc, n), nullptr, a.tile_cap * BX};
+    AccT<LMASK> acc{acc_of(s.acc, n), nullptr, a.cap * BX};
 
     auto cell_of = [&](int j) {
-        const int zr = j / tw, xs = j - zr * tw;
+        const uint32_t d = segs[j];
         Cell c;
-        c.z = __builtin_amdgcn_readfirstlane(t.z0 + zr);
-        c.x = (t.s0 + xs) * BX + lane;
+        c.z = __builtin_amdgcn_readfirstlane((int)(d & 0xffffu));
+        c.x = (int)((d >> 16) & 0xffu) * BX + lane;
         c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
         return c;
     };
@@ -1093,9 +1081,9 @@ const OptField kOptFields[] = {
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 31},   {"pk_wpc", &KernelOptions::pk_wpc, 1, 8},
-    {"pk_waves", &KernelOptions::pk_waves, 1, 16},   {"pk_px", &KernelOptions::pk_px, 0, 64},
+    {"pk_waves", &KernelOptions::pk_waves, 1, 16},   {"pk_px", &KernelOptions::pk_px, 1, 64},
     {"pk_chunk", &KernelOptions::pk_chunk, 0, 1 << 20},
-    {"pk_flags", &KernelOptions::pk_flags, 0, 7},
+    {"pk_flags", &KernelOptions::pk_flags, 0, 7}, {"pk_order", &KernelOptions::pk_order, 0, 1},
 };
 }  // namespace
 
@@ -1205,38 +1193,16 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
-// Tile geometry of the persistent backward loop for `nwg` resident workgroups: nband bands x pz x px tiles, tiles about four
-// row segments wide (x-halo columns are whole 256-B segments, z-halo rows are two rows: wide-ish tiles keep both small).
-void persist_geometry(const Grid &g0, int nwg, int nband, int px_opt, PersistArgs *a, int *max_segments) {
-    const int nseg = (g0.nx + BX - 1) / BX;
-    const int per_band = nwg / nband;
-    int best_px = 1, best_cost = 1 << 30;
-    for (int px = 1; px <= per_band; px++) {
-        if (per_band % px || px > nseg) continue;
-        const int pz = per_band / px;
-        const int rows = (g0.nzc + nband - 1) / nband;
-        const int th = (rows + pz - 1) / pz, tw = (nseg + px - 1) / px;
-        const int cost = (th + 4) * (tw * BX + 2 * BX);  // cells a tile touches, x halo priced as a whole segment per side
-        if (px_opt ? px == px_opt : cost < best_cost) {
-            best_cost = cost;
-            best_px = px;
-        }
-    }
-    a->nband = nband;
-    a->px = best_px;
-    a->pz = per_band / best_px;
-    const int rows = (g0.nzc + nband - 1) / nband;
-    *max_segments = ((rows + a->pz - 1) / a->pz) * ((nseg + a->px - 1) / a->px);
-}
-
 int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs *d_args, int nwg, int threads,
                        int lmask, size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
     Grid g = tiled(g0, o, 1);
     void (*k)(Grid, const PersistArgs *) = nullptr;
 #define PK(L, F) if (lmask == L && o.pk_flags == F) k = k_bwd_persist<L, F>;
-    PK(0, 0) PK(7, 0) PK(24, 0) PK(31, 0)
-    PK(0, 1) PK(7, 1) PK(0, 3) PK(7, 3) PK(7, 2) PK(0, 2)
-    PK(0, 4) PK(7, 4) PK(0, 5) PK(7, 5) PK(7, 7) PK(0, 7)
+    PK(0, 0) PK(7, 0) PK(15, 0) PK(31, 0)
+    PK(0, 1) PK(7, 1) PK(15, 1) PK(31, 1)
+    PK(0, 3) PK(7, 3) PK(15, 3)
+    PK(0, 5) PK(7, 5) PK(15, 5) PK(31, 5)
+    PK(0, 7) PK(7, 7) PK(15, 7)
 #undef PK
     if (!k) return -1;
     if (lds_bytes > 64 * 1024 &&

@@ -28,7 +28,8 @@ struct KernelOptions {
     int pk_lmask = 7;     // persistent backward loop (bwd_fuse = 4): which imaging accumulators stay in LDS (bit 0 lam, 1 mu, 2 xz, 3 a, 4 b)
     int pk_wpc = 1;       //   workgroups per CU
     int pk_waves = 16;    //   waves per workgroup
-    int pk_px = 0;        //   tiles across x per band (0: chosen by persist_geometry)
+    int pk_px = 4;        //   strip width of the tiling in row segments (persist_plan.hpp)
+    int pk_order = 1;     //   1: edge segments first in every phase (needed by the synchronised form), 0: the tiling's natural order
     int pk_flags = 0;     //   probe switches of k_bwd_persist
     int pk_chunk = 0;     //   time steps per launch (0: the whole pass)
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
@@ -61,8 +62,7 @@ void launch_bwd_a_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it);
 void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// persistent backward time loop: tile geometry for `nwg` workgroups and the launch (0, or < 0 when the grid cannot be resident)
-void persist_geometry(const Grid &g, int nwg, int nband, int px_opt, PersistArgs *a, int *max_segments);
+// persistent backward time loop (tiles: persist_plan.hpp): the launch (0, or < 0 when the grid cannot be resident)
 int launch_bwd_persist(hipStream_t st, const Grid &g, const KernelOptions &o, const PersistArgs *d_args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);

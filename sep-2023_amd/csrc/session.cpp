@@ -20,6 +20,7 @@
 
 #include "device_alloc.hpp"
 #include "kernels.hpp"
+#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -240,6 +241,8 @@ Session::~Session() {
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
     if (stf_grad_) (void)hipFree(stf_grad_);
+    if (plan_seg_) (void)hipFree(plan_seg_);
+    if (plan_hdr_) (void)hipFree(plan_hdr_);
     if (h_io_) (void)hipHostFree(h_io_);
     for (auto &e : ev_) (void)hipEventDestroy(e);
     for (auto &e : probe_ev_) (void)hipEventDestroy(e);
@@ -843,12 +846,28 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         const int nband = 8, threads = 64 * opt.pk_waves;
         const int nwg = (dev_cus / nband) * nband * opt.pk_wpc;
         PersistArgs a{};
-        int max_seg = 0;
-        persist_geometry(g, nwg, nband, opt.pk_px, &a, &max_seg);
+        const int nseg = (g.nx + 63) / 64;
+        if (plan_.nwg != nwg || plan_.strip_w != opt.pk_px || plan_order_ != opt.pk_order) {  // (re)build and upload the tiling
+            const std::string why = make_persist_plan(g.nzc, nseg, nwg, nband, opt.pk_px, &plan_, opt.pk_order != 0);
+            plan_order_ = opt.pk_order;
+            if (!why.empty()) throw std::invalid_argument(why);
+            if (plan_seg_) (void)hipFree(plan_seg_);
+            if (plan_hdr_) (void)hipFree(plan_hdr_);
+            plan_seg_ = nullptr;
+            plan_hdr_ = nullptr;
+            HIP_OK(dev_malloc((void **)&plan_seg_, plan_.seg.size() * sizeof(uint32_t)));
+            HIP_OK(dev_malloc((void **)&plan_hdr_, plan_.hdr.size() * sizeof(TileHdr)));
+            HIP_OK(hipMemcpy(plan_seg_, plan_.seg.data(), plan_.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(plan_hdr_, plan_.hdr.data(), plan_.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
+        }
+        a.nband = nband;
+        a.per_band = plan_.per_band;
+        a.cap = plan_.cap;
+        a.seg = plan_seg_;
+        a.hdr = plan_hdr_;
         int nl = 0;
         for (int k = 0; k < 5; k++) nl += (opt.pk_lmask >> k) & 1;
-        a.tile_cap = max_seg;
-        const size_t lds_bytes = (size_t)nl * (size_t)max_seg * 64 * sizeof(float);
+        const size_t lds_bytes = (size_t)nl * (size_t)plan_.cap * 64 * sizeof(float);
         ShotDev &d = a.s;
         d.fields = c.state;
         d.frame = c.frame;

@@ -14,6 +14,7 @@
 #include "config.hpp"
 #include "fwi_types.hpp"
 #include "kernels.hpp"
+#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -106,6 +107,10 @@ class Session {
     PersistArgs *persist_args_ = nullptr;
     unsigned int *persist_flags_ = nullptr;
     float *persist_stf_ = nullptr;
+    PersistPlan plan_;
+    int plan_order_ = -1;
+    uint32_t *plan_seg_ = nullptr;
+    TileHdr *plan_hdr_ = nullptr;
     int *rec_idx_ = nullptr;
     float *sens_ = nullptr;  // directional DAS sensitivities (3 per channel) or null
     // data conditioning (parameter keys if_win / filter / if_cross_misfit): per-channel windows and weights (3 per channel:
