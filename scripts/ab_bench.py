@@ -18,7 +18,7 @@ from sepfwi import _native, fwi_ops
 
 
 DEFAULTS = dict(bz=2, xcd_remap=1, bwd_fuse=2, line_fuse=1, pair_fwd=1, fwd_lanes=3, early=0, rho_fly=1, amu_fly=1, rk_lazy=1, batch=2, batch_f=0,
-                batch_b=0, batch_mb=200, batch_order=1, img_every=1, pk_lmask=7, pk_wpc=1, pk_waves=16, pk_px=4, pk_chunk=0, pk_flags=0, pk_order=1)
+                batch_b=0, batch_mb=200, batch_order=1, img_every=1)
 
 
 def main():
@@ -52,7 +52,7 @@ def main():
                     _native.check(L.sepfwi_set_option(k.encode(), int(val)))
                 try:
                     out = fwi_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
-                except RuntimeError as e:   # e.g. a persistent grid that cannot be resident
+                except RuntimeError as e:   # a variant the library refuses
                     if r == 0:
                         print("variant %s failed: %s" % (v, str(e)[:200]))
                     continue

@@ -104,22 +104,6 @@ struct ShotDev {
     float src_rxz;
 };
 
-// Device-resident argument block of the persistent backward time loop (k_bwd_persist): one shot, time steps it_hi ... it_lo.
-struct PersistArgs {
-    ShotDev s;
-    const float *media, *cz;  // media bundle (stride n), C-PML profile bundle
-    size_t n;
-    int it_hi, it_lo;
-    float src_scale;
-    int img_every;
-    int nband, per_band;  // tiles: nband row bands (one per XCD) x per_band tiles
-    int cap;              // slots per tile in `seg`, and row segments per LDS-resident accumulator array
-    const uint32_t *seg;  // [tiles][cap] segment descriptors (persist_plan.hpp)
-    const struct TileHdr *hdr;
-    unsigned int *flags;  // per tile: phases completed
-    int *err;
-};
-
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step
     float *buf;  // [nSteps][5][frame_len]  order: szz, sxz, sxx, vz, vx (Boundary.cu:57-80)
 };

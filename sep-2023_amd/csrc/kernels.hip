@@ -32,7 +32,6 @@
 
 #include "device_common.hpp"
 #include "kernels.hpp"
-#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -103,46 +102,16 @@ __device__ __forceinline__ float ave_mu_at(const Grid &g, const Media &md, size_
     return md.ave_mu[i];
 }
 
-
-// Imaging accumulators behind an accessor, so that the same bodies serve the per-step launches (accumulators in HBM, AccG)
-// and the persistent time loop (accumulators of the workgroup's own tile in LDS, AccT below).
-enum { ACC_LAM = 0, ACC_MU = 1, ACC_XZ = 2, ACC_A = 3, ACC_B = 4 };
-template <int K>
-__device__ __forceinline__ float *acc_array(const ImgAcc &a) {
-    return K == ACC_LAM ? a.lam : K == ACC_MU ? a.mu : K == ACC_XZ ? a.xz : K == ACC_A ? a.a : a.b;
-}
-struct AccG {
-    ImgAcc p;
-    template <int K> __device__ __forceinline__ float ld(size_t i) const { return acc_array<K>(p)[i]; }
-    template <int K> __device__ __forceinline__ void st(size_t i, float v) const { acc_array<K>(p)[i] = v; }
-};
-typedef __attribute__((address_space(3))) float lds_float;
-// MASK bit K set: accumulator K of this lane's cell lives in LDS at cell[rank of K among the set bits * stride]
-template <int MASK>
-struct AccT {
-    ImgAcc p;
-    lds_float *cell;  // this lane's slot of the current row segment
-    int stride;       // floats between two LDS-resident accumulator arrays of the tile
-    template <int K> __device__ __forceinline__ float ld(size_t i) const {
-        if constexpr ((MASK >> K) & 1) return cell[__builtin_popcount(MASK & ((1 << K) - 1)) * stride];
-        else return acc_array<K>(p)[i];
-    }
-    template <int K> __device__ __forceinline__ void st(size_t i, float v) const {
-        if constexpr ((MASK >> K) & 1) cell[__builtin_popcount(MASK & ((1 << K) - 1)) * stride] = v;
-        else acc_array<K>(p)[i] = v;
-    }
-};
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // stress update
 // ---------------------------------------------------------------------------------------------
-template <bool FWD, bool SAVE, class ACC>
+template <bool FWD, bool SAVE>
 __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
-                                            const Fields &adj, const ACC &acc, const LineRec &lr) {
+                                            const Fields &adj, const ImgAcc &acc, const LineRec &lr) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -231,7 +200,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             float za = 0.f, xa = 0.f, sa = 0.f, g_lam = 0.f, g_mu = 0.f, g_xz = 0.f;
             if (img) {
                 za = adj.szz[i]; xa = adj.sxx[i]; sa = adj.sxz[i];
-                g_lam = acc.template ld<ACC_LAM>(i); g_mu = acc.template ld<ACC_MU>(i); g_xz = acc.template ld<ACC_XZ>(i);
+                g_lam = acc.lam[i]; g_mu = acc.mu[i]; g_xz = acc.xz[i];
             }
             const float l2m = lam + 2.0f * mu;
             szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
@@ -239,9 +208,9 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             sxz -= amu * (dvx_dz + dvz_dx) * g.dt;
             if (img) {
                 // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
-                acc.template st<ACC_LAM>(i, g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img);
-                acc.template st<ACC_MU>(i, g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img);
-                acc.template st<ACC_XZ>(i, g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img);
+                acc.lam[i] = g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img;
+                acc.mu[i] = g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img;
+                acc.xz[i] = g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img;
             }
         }
         if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
@@ -275,11 +244,11 @@ __device__ __forceinline__ void buoyancies(const Grid &g, const Media &md, size_
     }
 }
 
-template <bool FWD, class ACC>
+template <bool FWD>
 __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
                                               float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
-                                              const ACC &acc) {
+                                              const ImgAcc &acc) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -326,7 +295,7 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             const bool img = g.dt_img != 0.0f;  // launch-uniform
             float g_a = 0.f, g_b = 0.f, avz = 0.f, avx = 0.f;
             if (img) {
-                g_a = acc.template ld<ACC_A>(i); g_b = acc.template ld<ACC_B>(i); avz = adj.vz[i]; avx = adj.vx[i];
+                g_a = acc.a[i]; g_b = acc.b[i]; avz = adj.vz[i]; avx = adj.vx[i];
             }
             float ba, bb;
             buoyancies(g, md, i, ba, bb);
@@ -334,8 +303,8 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             vx = f.vx[i] - (dsxz_dz + dsxx_dx) * bb * g.dt;
             if (img) {
                 // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
-                acc.template st<ACC_A>(i, g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img);
-                acc.template st<ACC_B>(i, g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img);
+                acc.a[i] = g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img;
+                acc.b[i] = g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img;
             }
         }
         if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
@@ -545,13 +514,13 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
 template <bool FWD, bool SAVE>
 __global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
                                                  int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc, LineRec lr) {
-    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
+    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr);
 }
 template <bool FWD>
 __global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
                                                    const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
                                                    float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
-    velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
+    velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     velocity_adj_body(g, my_cell(g), f, m, md, pc, LineRec{});
@@ -607,10 +576,10 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
     const Cell c = my_cell(g);
     if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
@@ -630,10 +599,10 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
     if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
     if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
         velocity_adj_body(g, c, adj, m, md, pc, lr);
     }
 }
@@ -668,7 +637,7 @@ __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev
         lr.d_vz = (s.comps & 4) ? s.syn + 2 * data_len + c0 : nullptr;
         lr.d_ett = (s.comps & 8) ? s.syn + 3 * data_len + c0 : nullptr;
     }
-    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, AccG{}, lr);
+    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, ImgAcc{}, lr);
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                              const float *__restrict__ cz, size_t n) {
@@ -679,7 +648,7 @@ __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotD
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
-    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, AccG{});
+    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, ImgAcc{});
 }
 template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
@@ -695,10 +664,10 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__r
     const float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
     if constexpr (EARLY) {
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
@@ -719,120 +688,11 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
     if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
     if constexpr (EARLY) {
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
         velocity_adj_body(g, c, adj, m, md, pc, lr);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent backward time loop (option bwd_fuse = 4): ONE launch advances a shot through many backward time steps.
-// The grid is occupancy-sized (every workgroup resident at once); a workgroup owns a fixed tile of
-// 64-column row segments for the whole launch and walks it twice per time step: phase A = the k_bwd_a bodies,
-// phase B = the k_bwd_b bodies (same bodies, same order of operations on every array: Src/libCUFD.cu:545-631).
-// Fixed ownership is what the per-step launches cannot have: the imaging accumulators of the tile never leave
-// the CU (LDS; template mask LMASK), and there is no grid fill / drain between the 2 x 3999 phases of a pass.
-// Tiles come from a host-built plan (persist_plan.hpp): per workgroup a list of row segments (edge segments first), every
-// tile the same size +- 1; band = blockIdx % nband is the XCD under round-robin dispatch.
-// ---------------------------------------------------------------------------------------------
-// FLAGS (probe): 1 segments handed out wave by wave from an LDS counter instead of a fixed stride, 2 no workgroup barrier
-// between phases (timing only), 4 registers capped for 8 waves per SIMD
-template <int LMASK, int FLAGS>
-__global__ __launch_bounds__(MAXT, (FLAGS & 4) ? 8 : 4) void k_bwd_persist(Grid g, const PersistArgs *__restrict__ pa) {
-    extern __shared__ float lds_dyn[];
-    __shared__ int next_item;
-    if (threadIdx.x == 0) next_item = 0;
-    const PersistArgs &a = *pa;
-    const ShotDev &s = a.s;
-    const size_t n = a.n;
-    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
-    const PmlMem m = mem_of(s.bmem, n);
-    const Media md = media_of(a.media, n);
-    const PmlCoef pc = coef_of(a.cz, a.cz + 6 * g.nzc, g.nzc, g.nx);
-    const int tile = (int)(blockIdx.x % a.nband) * a.per_band + (int)(blockIdx.x / a.nband);
-    const TileHdr &h = a.hdr[tile];
-    const uint32_t *__restrict__ segs = a.seg + (size_t)tile * (size_t)a.cap;
-    const int nst = h.n_seg;
-    const int lane = threadIdx.x & (BX - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
-    lds_float *const lbase = (lds_float *)lds_dyn;
-    AccT<LMASK> acc{acc_of(s.acc, n), nullptr, a.cap * BX};
-
-    auto cell_of = [&](int j) {
-        const uint32_t d = segs[j];
-        Cell c;
-        c.z = __builtin_amdgcn_readfirstlane((int)(d & 0xffffu));
-        c.x = (int)((d >> 16) & 0xffu) * BX + lane;
-        c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
-        return c;
-    };
-    // prologue: the tile's accumulators HBM -> LDS (they carry the sum over the shots of the call)
-    if constexpr (LMASK != 0) {
-        for (int j = wave; j < nst; j += nw) {
-            const Cell c = cell_of(j);
-            lds_float *cell = lbase + j * BX + lane;
-            int r = 0;
-            if constexpr (LMASK & 1) cell[(r++) * acc.stride] = acc.p.lam[c.i];
-            if constexpr (LMASK & 2) cell[(r++) * acc.stride] = acc.p.mu[c.i];
-            if constexpr (LMASK & 4) cell[(r++) * acc.stride] = acc.p.xz[c.i];
-            if constexpr (LMASK & 8) cell[(r++) * acc.stride] = acc.p.a[c.i];
-            if constexpr (LMASK & 16) cell[(r++) * acc.stride] = acc.p.b[c.i];
-        }
-    }
-    __syncthreads();
-
-    auto grab = [&]() {  // next work item of the workgroup: (step, phase, segment) in execution order
-        int v = 0;
-        if (lane == 0) v = atomicAdd(&next_item, 1);
-        return __builtin_amdgcn_readfirstlane(v);
-    };
-    int w = (FLAGS & 1) ? grab() : wave;
-    for (int it = a.it_hi; it >= a.it_lo; it--) {
-        Grid gs = g;
-        if (a.img_every > 1) gs.dt_img = (it % a.img_every == 0) ? (float)a.img_every * g.dt : 0.0f;
-        float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
-        // ---- phase A: reverse-time velocity (+ rho imaging, frame restore) + adjoint stress of the previous step
-        int base = (a.it_hi - it) * 2 * nst;
-        for (; w < base + nst; w = (FLAGS & 1) ? grab() : w + nw) {
-            const int j = w - base;
-            const Cell c = cell_of(j);
-            acc.cell = lbase + j * BX + lane;
-            velocity_body<false>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
-            stress_adj_body(gs, c, adj, m, md, pc);
-        }
-        if constexpr (!(FLAGS & 2)) __syncthreads();
-        // ---- phase B: source_grad + reverse-time stress (+ lambda/mu imaging, frame restore) + adjoint velocity + injection
-        const float amp = __fmul_rn(__fmul_rn(a.src_scale, s.stf[it]), g.dt);
-        const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
-        base += nst;
-        if constexpr (!(FLAGS & 1)) w = base + wave;
-        for (; w < base + nst; w = (FLAGS & 1) ? grab() : w + nw) {
-            const int j = w - base;
-            const Cell c = cell_of(j);
-            acc.cell = lbase + j * BX + lane;
-            if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
-            stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
-            velocity_adj_body(gs, c, adj, m, md, pc, lr);
-        }
-        if constexpr (!(FLAGS & 2)) __syncthreads();
-        if constexpr (!(FLAGS & 1)) w = base + nst + wave;
-    }
-    __syncthreads();
-
-    // epilogue: LDS -> HBM
-    if constexpr (LMASK != 0) {
-        for (int j = wave; j < nst; j += nw) {
-            const Cell c = cell_of(j);
-            lds_float *cell = lbase + j * BX + lane;
-            int r = 0;
-            if constexpr (LMASK & 1) acc.p.lam[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 2) acc.p.mu[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 4) acc.p.xz[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 8) acc.p.a[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 16) acc.p.b[c.i] = cell[(r++) * acc.stride];
-        }
     }
 }
 
@@ -1071,7 +931,7 @@ struct OptField {
 };
 const OptField kOptFields[] = {
     {"bz", &KernelOptions::bz, 1, 16},           {"xcd_remap", &KernelOptions::xcd_remap, 0, 1},
-    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 4}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
+    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 2}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
     {"pair_fwd", &KernelOptions::pair_fwd, 0, 1}, {"fwd_lanes", &KernelOptions::fwd_lanes, 1, 4},
     {"early", &KernelOptions::early, 0, 3},       {"rho_fly", &KernelOptions::rho_fly, 0, 3},
     {"amu_fly", &KernelOptions::amu_fly, 0, 3},   {"rk_lazy", &KernelOptions::rk_lazy, 0, 1},
@@ -1080,10 +940,6 @@ const OptField kOptFields[] = {
     {"batch_order", &KernelOptions::batch_order, 0, 1},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
-    {"pk_lmask", &KernelOptions::pk_lmask, 0, 31},   {"pk_wpc", &KernelOptions::pk_wpc, 1, 8},
-    {"pk_waves", &KernelOptions::pk_waves, 1, 16},   {"pk_px", &KernelOptions::pk_px, 1, 64},
-    {"pk_chunk", &KernelOptions::pk_chunk, 0, 1 << 20},
-    {"pk_flags", &KernelOptions::pk_flags, 0, 7}, {"pk_order", &KernelOptions::pk_order, 0, 1},
 };
 }  // namespace
 
@@ -1100,7 +956,7 @@ int set_kernel_option(const char *name, int value) {
     std::lock_guard<std::mutex> lock(g_opt_mu);
     for (const OptField &f : kOptFields)
         if (n == f.name) {
-            if (value < f.lo || value > f.hi || (n == "bwd_fuse" && (value == 1 || value == 3))) return -1;
+            if (value < f.lo || value > f.hi || (n == "bwd_fuse" && value == 1)) return -1;
             g_opt.*(f.field) = value;
             return 0;
         }
@@ -1191,34 +1047,6 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
     else
         hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
-}
-
-int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs *d_args, int nwg, int threads,
-                       int lmask, size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    Grid g = tiled(g0, o, 1);
-    void (*k)(Grid, const PersistArgs *) = nullptr;
-#define PK(L, F) if (lmask == L && o.pk_flags == F) k = k_bwd_persist<L, F>;
-    PK(0, 0) PK(7, 0) PK(15, 0) PK(31, 0)
-    PK(0, 1) PK(7, 1) PK(15, 1) PK(31, 1)
-    PK(0, 3) PK(7, 3) PK(15, 3)
-    PK(0, 5) PK(7, 5) PK(15, 5) PK(31, 5)
-    PK(0, 7) PK(7, 7) PK(15, 7)
-#undef PK
-    if (!k) return -1;
-    if (lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-        return -2;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, threads, lds_bytes) != hipSuccess) return -3;
-    int dev = 0, ncu = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (per_cu * ncu < nwg) return -4;  // the grid would not be resident at once
-    if (ev_start)
-        hipExtLaunchKernelGGL(k, dim3(nwg), dim3(threads), lds_bytes, st, ev_start, ev_stop, 0, g, d_args);
-    else
-        hipLaunchKernelGGL(k, dim3(nwg), dim3(threads), lds_bytes, st, g, d_args);
-    return 0;
 }
 
 __global__ void k_add_inplace(float *__restrict__ a, const float *__restrict__ b, size_t n) {

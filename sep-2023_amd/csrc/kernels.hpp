@@ -25,13 +25,6 @@ struct KernelOptions {
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
-    int pk_lmask = 7;     // persistent backward loop (bwd_fuse = 4): which imaging accumulators stay in LDS (bit 0 lam, 1 mu, 2 xz, 3 a, 4 b)
-    int pk_wpc = 1;       //   workgroups per CU
-    int pk_waves = 16;    //   waves per workgroup
-    int pk_px = 4;        //   strip width of the tiling in row segments (persist_plan.hpp)
-    int pk_order = 1;     //   1: edge segments first in every phase (needed by the synchronised form), 0: the tiling's natural order
-    int pk_flags = 0;     //   probe switches of k_bwd_persist
-    int pk_chunk = 0;     //   time steps per launch (0: the whole pass)
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)
 };
@@ -62,9 +55,6 @@ void launch_bwd_a_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it);
 void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// persistent backward time loop (tiles: persist_plan.hpp): the launch (0, or < 0 when the grid cannot be resident)
-int launch_bwd_persist(hipStream_t st, const Grid &g, const KernelOptions &o, const PersistArgs *d_args, int nwg, int threads, int lmask,
-                       size_t lds_bytes, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps, const float *sens = nullptr);

@@ -20,7 +20,6 @@
 
 #include "device_alloc.hpp"
 #include "kernels.hpp"
-#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -121,10 +120,6 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     grad_stage_ = dalloc<float>(3 * dense);
     scal_ = dalloc<double>(4);
     cp2_bits_ = dalloc<unsigned int>(4);
-    persist_args_ = dalloc<PersistArgs>(kPersistSlots);
-    persist_flags_ = dalloc<unsigned int>(kPersistFlags);
-    persist_stf_ = dalloc<float>((size_t)par.nSteps);
-    HIP_OK(hipMemset(persist_flags_, 0, kPersistFlags * sizeof(unsigned int)));
 
     // ---- C-PML profiles (host) -> device, with 1/K precomputed ----
     {
@@ -241,8 +236,6 @@ Session::~Session() {
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
     if (stf_grad_) (void)hipFree(stf_grad_);
-    if (plan_seg_) (void)hipFree(plan_seg_);
-    if (plan_hdr_) (void)hipFree(plan_hdr_);
     if (h_io_) (void)hipHostFree(h_io_);
     for (auto &e : ev_) (void)hipEventDestroy(e);
     for (auto &e : probe_ev_) (void)hipEventDestroy(e);
@@ -816,7 +809,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         Grid gs = g;  // this step's imaging weight (option img_every)
         if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-        if (fuse_bwd == 2 || fuse_bwd == 4) {
+        if (fuse_bwd == 2) {
             launch_bwd_a(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
             launch_bwd_b(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
             if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
@@ -839,80 +832,11 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
         }
         n_probe = 0;
     };
-    // the whole backward pass of one shot as persistent launches (option bwd_fuse = 4; kernels.hip k_bwd_persist)
-    auto backward_persistent = [&](const ShotCtx &c, const BwdLane &L) {
-        int dev_cus = 0;
-        HIP_OK(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, gpu_id_));
-        const int nband = 8, threads = 64 * opt.pk_waves;
-        const int nwg = (dev_cus / nband) * nband * opt.pk_wpc;
-        PersistArgs a{};
-        const int nseg = (g.nx + 63) / 64;
-        if (plan_.nwg != nwg || plan_.strip_w != opt.pk_px || plan_order_ != opt.pk_order) {  // (re)build and upload the tiling
-            const std::string why = make_persist_plan(g.nzc, nseg, nwg, nband, opt.pk_px, &plan_, opt.pk_order != 0);
-            plan_order_ = opt.pk_order;
-            if (!why.empty()) throw std::invalid_argument(why);
-            if (plan_seg_) (void)hipFree(plan_seg_);
-            if (plan_hdr_) (void)hipFree(plan_hdr_);
-            plan_seg_ = nullptr;
-            plan_hdr_ = nullptr;
-            HIP_OK(dev_malloc((void **)&plan_seg_, plan_.seg.size() * sizeof(uint32_t)));
-            HIP_OK(dev_malloc((void **)&plan_hdr_, plan_.hdr.size() * sizeof(TileHdr)));
-            HIP_OK(hipMemcpy(plan_seg_, plan_.seg.data(), plan_.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(plan_hdr_, plan_.hdr.data(), plan_.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
-        }
-        a.nband = nband;
-        a.per_band = plan_.per_band;
-        a.cap = plan_.cap;
-        a.seg = plan_seg_;
-        a.hdr = plan_hdr_;
-        int nl = 0;
-        for (int k = 0; k < 5; k++) nl += (opt.pk_lmask >> k) & 1;
-        const size_t lds_bytes = (size_t)nl * (size_t)plan_.cap * 64 * sizeof(float);
-        ShotDev &d = a.s;
-        d.fields = c.state;
-        d.frame = c.frame;
-        d.stf = persist_stf_;
-        d.bmem = L.bm.dvz_dz;
-        d.adj = L.adj.vz;
-        d.acc = L.acc.lam;
-        d.res = c.res;
-        d.stf_grad = stf_grad_ + (size_t)c.is * nSteps;
-        d.z_src = c.sh->z_src;
-        d.x_src = c.sh->x_src;
-        d.lr_z = c.line.z;
-        d.lr_x0 = c.line.x0;
-        d.lr_n = c.line.n;
-        d.nrec = c.nrec;
-        d.src_rxz = (float)c.sh->src_rxz;
-        a.media = md_.lam;
-        a.cz = pc_.a_z;
-        a.n = n;
-        a.src_scale = src_scale;
-        a.img_every = opt.img_every;
-        a.flags = persist_flags_;
-        a.err = (int *)(persist_flags_ + kPersistFlags - 1);
-        HIP_OK(hipMemcpyAsync(persist_stf_, c.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, L.s));
-        const int chunk = opt.pk_chunk > 0 ? opt.pk_chunk : nSteps;
-        int slot = 0;
-        for (int hi = nSteps - 2; hi >= 0; hi -= chunk, slot++) {
-            a.it_hi = hi;
-            a.it_lo = std::max(0, hi - chunk + 1);
-            if (slot >= kPersistSlots) throw std::invalid_argument("pk_chunk: too many launches per pass");
-            HIP_OK(hipMemcpyAsync(persist_args_ + slot, &a, sizeof(a), hipMemcpyHostToDevice, L.s));
-            HIP_OK(hipStreamSynchronize(L.s));  // `a` is pageable host memory
-            const int rc = launch_bwd_persist(L.s, g, opt, persist_args_ + slot, nwg, threads, opt.pk_lmask, lds_bytes);
-            if (rc != 0) throw HipError("persistent backward loop cannot be launched (code " + std::to_string(rc) + "): grid not resident or LDS too small");
-            launches_++;
-        }
-    };
     auto backward = [&](const ShotCtx &c) {
         const BwdLane L{st, mem_, adj_, acc_};
         HIP_OK(hipEventRecord(ev_[2], st));
         backward_init(L);
-        if (fuse_bwd == 4 && (c.nrec == 0 || (c.line.n > 0 && opt.line_fuse != 0)))
-            backward_persistent(c, L);
-        else
-            for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
+        for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
         HIP_OK(hipEventRecord(ev_[3], st));
         bwd_steps_ += (long long)(nSteps - 1);
         HIP_OK(hipStreamSynchronize(st));

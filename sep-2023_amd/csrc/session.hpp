@@ -14,7 +14,6 @@
 #include "config.hpp"
 #include "fwi_types.hpp"
 #include "kernels.hpp"
-#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -102,15 +101,6 @@ class Session {
     float *frame_ = nullptr, *syn_ = nullptr, *res_ = nullptr, *xpose_ = nullptr, *stf_grad_ = nullptr, *h_io_ = nullptr;
     double *scal_ = nullptr;
     unsigned int *cp2_bits_ = nullptr;
-    // persistent backward time loop: argument blocks (one per launch of a pass), tile flags, the shot's tapered source trace
-    static constexpr int kPersistSlots = 64, kPersistFlags = 4096;
-    PersistArgs *persist_args_ = nullptr;
-    unsigned int *persist_flags_ = nullptr;
-    float *persist_stf_ = nullptr;
-    PersistPlan plan_;
-    int plan_order_ = -1;
-    uint32_t *plan_seg_ = nullptr;
-    TileHdr *plan_hdr_ = nullptr;
     int *rec_idx_ = nullptr;
     float *sens_ = nullptr;  // directional DAS sensitivities (3 per channel) or null
     // data conditioning (parameter keys if_win / filter / if_cross_misfit): per-channel windows and weights (3 per channel:

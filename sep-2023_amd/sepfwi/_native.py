@@ -12,8 +12,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
-SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "config.cpp", "capi.cpp", "persist_plan.cpp"]
-HEADERS = ["kernels.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "persist_plan.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "config.cpp", "capi.cpp"]
+HEADERS = ["kernels.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
 _lib = None
