@@ -39,6 +39,9 @@ BYTES_FWD = 60.0
 # lambda,mu,ave_mu 12 + grad lambda,mu r/w 16 = 68 B per cell per launch (k_bwd_a owns the other 56 B: vz,vx r/w 16 +
 # adjoint szz,sxx,sxz r/w 24 + byc_a,byc_b 8 + grad rho r/w 8); DESIGN.md "Kernels and rooflines".
 BYTES_K_BWD_STRESS = 68.0
+# The same apportioning for the other three field kernels (each array charged to the kernel that read-modify-writes it, the
+# coefficients to the kernel that needs them): PMC bytes / these = `roofline.traffic_ratio`.
+ALGO_BYTES_PER_CELL = {"k_bwd_b": 68.0, "k_bwd_a": 56.0, "k_stress_fwd_save": 36.0, "k_velocity_fwd": 24.0}
 
 
 def marmousi_style(nz, nx, seed=2023, pert_amp=0.1, sigma_init=40.0):
@@ -227,6 +230,28 @@ def launcher_cmd(n_gpus, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def call32(workdir, args, dev, local, n_shots=32):
+    """BASELINE.json configs[2] as one call: 32 shots, forward + boundary-saving adjoint gradient, one `fwi_ops.backward`.
+    Own survey (32 sources across the model), observed data modelled into the session's HBM store beforehand (untimed)."""
+    from sepfwi import fwi_ops
+    os.makedirs(workdir, exist_ok=True)
+    pb = setup_problem(workdir, args.nz, args.nx, args.nsteps, n_shots)
+    lam_t, mu_t, den_t = [t.to(dev) for t in pb["lame_true"]]
+    lam, mu, den = [t.to(dev) for t in pb["lame_init"]]
+    ids = torch.arange(n_shots, dtype=torch.int32)
+    fwi_ops._cufd(3, local, lam_t, mu_t, den_t, pb["Stf"], ids, pb["para_fname"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fwi_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = fwi_ops.stats(pb["para_fname"], local)
+    upd = n_shots * 3.0 * pb["n_c"] * (args.nsteps - 1)
+    return {"value": round(upd / el / 1e9, 4), "unit": "Gcell-updates/s", "ms": round(el * 1e3, 1), "shots": n_shots,
+            "device_ms": round(st["fwd_ms"] + st["bwd_ms"], 1),
+            "what": "one fwi_ops.backward over %d shots (configs[2]), wall time of the call, after the timed region" % n_shots}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +265,7 @@ def main():
     ap.add_argument("--shots-per-step", type=int, default=3,
                     help="shots each GPU processes per step (3: the forward passes of the three overlap on three streams)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--no-call32", action="store_true", help="skip the one 32-shot call of configs[2] reported as `call32` at N = 1")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box; use with --backend gloo)")
     args = ap.parse_args()
 
@@ -350,13 +376,18 @@ def main():
             # roofline of the dominant kernel group, measured live with HIP events on the session stream
             # (sepfwi_stats.fwd_ms / bwd_ms): algorithmic bytes per time step / measured time per time step.
             nst = K * spr * (args.nsteps - 1)
-            traffic = None
+            traffic = traffic_ratio = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
             if os.path.exists(tf) and args.nz == 1000 and args.nx == 2000:
                 tj = json.load(open(tf))
                 # the counters were collected on ONE version of the kernels: a changed kernel file makes them stale -> null
                 if tj.get("kernel_source_sha256") == kernel_source_digest():
                     traffic = tj.get("k_bwd_b_bytes_per_launch")
+                    # PMC bytes / algorithmic bytes, per kernel and per time step (1.0 = every array touched exactly once)
+                    pmc = {k: tj[k + "_bytes_per_launch"] for k in ALGO_BYTES_PER_CELL}
+                    traffic_ratio = {k: round(pmc[k] / (ALGO_BYTES_PER_CELL[k] * pb["n_c"]), 3) for k in pmc}
+                    traffic_ratio["bwd_step"] = round((pmc["k_bwd_a"] + pmc["k_bwd_b"]) / (124.0 * pb["n_c"]), 3)
+                    traffic_ratio["fwd_step"] = round((pmc["k_stress_fwd_save"] + pmc["k_velocity_fwd"]) / (BYTES_FWD * pb["n_c"]), 3)
             if args.mode == "fwdadj" and probe_n > 0:
                 per_step_us = probe_us / probe_n
                 ach = pb["n_c"] * BYTES_K_BWD_STRESS / (per_step_us * 1e-6) / 1e9
@@ -369,7 +400,7 @@ def main():
                 per_step_us = fwd_ms * 1e3 / nst
                 ach = pb["n_c"] * BYTES_FWD / (per_step_us * 1e-6) / 1e9
                 kern = "whole forward time step (k_stress<FWD> + k_velocity<FWD>)"
-                traffic = None
+                traffic = traffic_ratio = None
             out = {
                 "metric": "Gcell-updates/s (fwd+adj), %dx%d grid x %d steps" % (args.nx, args.nz, args.nsteps) if args.mode == "fwdadj" else "Gcell-updates/s (fwd)",
                 "value": round(value, 4), "unit": "Gcell-updates/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -380,7 +411,7 @@ def main():
                                                                         pb["nrec"], spr, "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
                            "cell_updates_per_shot": updates_per_shot, "shots_per_gpu_per_step": spr, "parallelism": "shots x%d" % world},
                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": kern,
+                             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_ratio": traffic_ratio, "kernel": kern,
                              "avg_us": round(per_step_us, 2),
                              "whole_job_frac": round(value * (BYTES_PER_UPDATE_FWDADJ if args.mode == "fwdadj" else BYTES_FWD) / world / HBM_PEAK_GBPS, 4),
                              # un-apportioned cross-checks from the session's own HIP-event timing of the time loops: 60 B per cell
@@ -402,6 +433,9 @@ def main():
                                "bytes": coll["bytes"], "allreduce_ms": round(min(rank_ar), 4), "allreduce_ms_max": round(max(rank_ar), 4),
                                "staged_copies": coll["staged"], "devices": "shared device 0 (rehearsal)" if args.share_gpu else "one per rank"}
             out["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}
+            if world == 1 and args.mode == "fwdadj" and not args.no_call32 and args.nz == 1000 and args.nx == 2000:
+                # configs[2] literally: ONE fwi_ops.backward call over 32 shots on this GPU (outside the timed region above)
+                out["call32"] = call32(os.path.join(workdir, "call32"), args, dev, local)
             if not args.no_cpu_baseline and world == 1:
                 out["cpu_baseline"] = cpu_baseline(args.nz, args.nx)
             print(json.dumps(out))

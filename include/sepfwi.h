@@ -157,7 +157,8 @@ int sepfwi_get_option(const char *name);
  * resize), mask blend P_m = Mask P_pad + (1 - Mask) P_ref (FWI_ops.py:120-122), the Lame map -- in ONE launch, and the
  * whole chain rule back to the (nz, nx) parameters (Lame derivatives, mask, transpose of the padding) in ONE.
  *   kind: 0 (Vp, Vs, Den) FWI_ops.py:124-125 | 1 (Lambda, Mu, Den) :204 | 2 (IP, IS, Den) :261-262 |
- *         3 (Vp, Vs, IP) :326-328 | 4 (Vp, Vs, IS) :389-391
+ *         3 (Vp, Vs, IP) :326-328 | 4 (Vp, Vs, IS) :389-391 | 5 (porosity, clay content, water saturation) Voigt-Reuss-Hill
+ *         :451-497 | 6 the same triple, Biot-Gassmann :567-611
  *   A, B, C            (nz, nx) physical grid;  *_ref, Mask, Lambda, Mu, Den, gLambda, gMu, gDen:
  *                      (nz + 2 nPml + nPad, nx + 2 nPml) padded grid; gA, gB, gC: (nz, nx).  All float32 row-major DEVICE
  *                      pointers of one device; launched on hip_stream (NULL: the default stream), not synchronised.

@@ -11,7 +11,9 @@ enum ParamKind {
     PARAM_IP_IS_DEN = 2,   // FWI_IP_IS_Den      FWI_ops.py:208-266
     PARAM_VP_VS_IP = 3,    // FWI_Vp_Vs_IP       FWI_ops.py:270-330
     PARAM_VP_VS_IS = 4,    // FWI_Vp_Vs_IS       FWI_ops.py:333-393
-    PARAM_KINDS = 5
+    PARAM_ROCK_VRH = 5,       // FWI_Rock_Physics_VRH       FWI_ops.py:401-497   (A, B, C) = (porosity, clay content, water saturation)
+    PARAM_ROCK_GASSMANN = 6,  // FWI_Rock_Physics_gassmann  FWI_ops.py:504-619
+    PARAM_KINDS = 7
 };
 
 void launch_param_fwd(hipStream_t st, int kind, int nz, int nx, int nPml, int nPad, const float *A, const float *B, const float *C,

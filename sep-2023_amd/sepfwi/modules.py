@@ -2,9 +2,8 @@
 
 These are the CALLERS of the operator boundary (reference: FWI_ops.py:66-619).  They work on CPU tensors exactly like
 the reference (pure torch) and, unlike it, on HIP tensors too (device-resident iteration): there the five algebraic
-parameterisations run as ONE fused HIP launch forward and ONE backward (csrc/param_maps.hip) instead of
-a dozen elementwise kernels over 3 x 9 MB; the two rock-physics maps stay torch expressions (on whatever device the
-tensors live).  Same class names, constructor signatures, attribute names (parameters `Vp`/`Vs`/`Den` ..., buffers
+parameterisations and the two rock-physics maps run as ONE fused HIP launch forward and ONE backward
+(csrc/param_maps.hip) instead of a dozen (rock physics: about forty) elementwise kernels over 3 x 9 MB.  Same class names, constructor signatures, attribute names (parameters `Vp`/`Vs`/`Den` ..., buffers
 `*_ref`, `Bounds`, `Mask`) and forward(Shot_ids, ngpu) contract, so obj_wrapper.PyTorchObjective and the experiment
 scripts work unchanged.  One generic base replaces the reference's copy-per-parameterisation.
 """
@@ -192,6 +191,7 @@ class FWI_Rock_Physics_VRH(_MaskedTriple):
     """Porosity, clay content, water saturation -> elastic moduli by the Voigt-Reuss-Hill average of a quartz / clay
     matrix with a water / hydrocarbon pore fill (FWI_ops.py:401-497; constants ft.ROCK)."""
     NAMES = ("PHI", "CC", "SW")
+    KIND = 5
 
     def __init__(self, PHI, CC, SW, Stf, opt, Mask=None, PHI_bounds=None, CC_bounds=None, SW_bounds=None):
         super().__init__(PHI, CC, SW, Stf, opt, Mask, (PHI_bounds, CC_bounds, SW_bounds))
@@ -213,6 +213,7 @@ class FWI_Rock_Physics_gassmann(_MaskedTriple):
     """Porosity, clay content, water saturation -> elastic moduli by Biot-Gassmann fluid substitution on a consolidation-
     parameter frame (FWI_ops.py:504-619, after PyFWI; constants ft.ROCK, cs = 20)."""
     NAMES = ("PHI", "CC", "SW")
+    KIND = 6
 
     def __init__(self, PHI, CC, SW, Stf, opt, Mask=None, PHI_bounds=None, CC_bounds=None, SW_bounds=None):
         super().__init__(PHI, CC, SW, Stf, opt, Mask, (PHI_bounds, CC_bounds, SW_bounds))

@@ -53,6 +53,49 @@ def test_fused_maps_equal_torch_expressions(tmp_path, hip_ops, cls_name):
         assert np.abs(outs["cuda"][k] - outs["cpu"][k]).max() <= 2e-6 * scale, (cls_name, "backward", k)
 
 
+@pytest.mark.parametrize("cls_name", ["FWI_Rock_Physics_VRH", "FWI_Rock_Physics_gassmann"])
+def test_fused_rock_physics_maps_equal_torch_expressions(tmp_path, hip_ops, cls_name):
+    """Kinds 5 and 6 of csrc/param_maps.hip (FWI_ops.py:451-497 Voigt-Reuss-Hill, :567-611 Biot-Gassmann): pad + mask blend +
+    rock-physics map in one launch and its whole chain rule in one, against the torch expressions on CPU tensors (the
+    reference's arrangement).  VRH forward: bit for bit (same float32 operations in the same order).  Gassmann forward: to two
+    units in the last place of the velocities -- it takes two square roots, and torch's vectorised CPU sqrt is itself not
+    correctly rounded (0.7 % of its results differ from IEEE sqrt by one ulp), so there is no bit pattern to match.  Chain rule:
+    reverse-mode over the same operation list as autograd, <= 1e-6 (VRH) / 1e-5 (Gassmann: the roots again) of the largest entry."""
+    from sepfwi import modules as M
+    pb = P.make_problem(str(tmp_path), nz=37, nx=70, nPml=9, nSteps=10, nshots=1, nPad=5)
+    rng = np.random.default_rng(11)
+    mask = (rng.uniform(size=(pb["nz_pad"], pb["nx_pad"])) > 0.3).astype(np.float32)
+    mask[20:30, 15:40] = rng.uniform(0.1, 0.9, (10, 25))
+    mask[:, :5] = 1.0; mask[-7:, :] = 1.0
+    fields = [P.smooth_random(rng, (37, 70), lo, hi).astype(np.float32) for lo, hi in ((0.10, 0.30), (0.05, 0.45), (0.2, 0.9))]
+    gl, gm, gd = [torch.tensor(rng.standard_normal((pb["nz_pad"], pb["nx_pad"])).astype(np.float32)) for _ in range(3)]
+    outs = {}
+    for dev in ("cpu", "cuda"):
+        f = [torch.tensor(a, device=dev, requires_grad=True) for a in fields]
+        ref = [torch.tensor((a * 1.03).astype(np.float32), device=dev) for a in fields]
+        mod = getattr(M, cls_name)(ref[0], ref[1], ref[2], pb["Stf"], pb["opt"], Mask=torch.tensor(mask, device=dev))
+        for n, t in zip(mod.NAMES, f):
+            setattr(mod, n, torch.nn.Parameter(t))
+        assert mod._fusable() == (dev == "cuda")
+        lam, mu, den = mod.lame_padded()
+        (lam * gl.to(dev)).sum().add((mu * gm.to(dev)).sum()).add((den * gd.to(dev)).sum()).backward()
+        outs[dev] = [t.detach().cpu().numpy() for t in (lam, mu, den)] + [getattr(mod, n).grad.cpu().numpy() for n in mod.NAMES]
+    if cls_name.endswith("VRH"):
+        for k in range(3):
+            assert np.array_equal(outs["cuda"][k], outs["cpu"][k]), (cls_name, "forward", k)
+    else:
+        lam_c, mu_c, den_c = outs["cpu"][:3]
+        assert np.array_equal(outs["cuda"][2], den_c)                      # the density has no root in it
+        np.testing.assert_allclose(outs["cuda"][1], mu_c, rtol=5e-7)       # rho vs^2: two ulp of vs
+        # Lambda = rho (vp^2 - 2 vs^2) / 1e6: two ulp of each velocity, measured against the minuend
+        m_c = den_c.astype(np.float64) * (lam_c.astype(np.float64) / den_c + 2 * mu_c.astype(np.float64) / den_c)
+        assert np.abs(outs["cuda"][0] - lam_c).max() <= 1e-6 * np.abs(m_c).max()
+    tol = 1e-6 if cls_name.endswith("VRH") else 1e-5
+    for k in range(3, 6):
+        scale = np.abs(outs["cpu"][k]).max()
+        assert scale > 0 and np.abs(outs["cuda"][k] - outs["cpu"][k]).max() <= tol * scale, (cls_name, "backward", k, np.abs(outs["cuda"][k] - outs["cpu"][k]).max() / scale)
+
+
 def test_fused_chain_on_gpu_equals_the_reference_chain_on_cpu_tensors(tmp_path, oracle, hip_ops):
     """The whole iteration (module -> FWIFunction -> HIP propagator -> chain rule): everything resident in HBM with the
     fused maps, against the reference's arrangement -- torch expressions on CPU tensors, model staged over PCIe.  The
@@ -119,8 +162,8 @@ def test_rock_physics_modules_on_hip_tensors(tmp_path, hip_ops, cls_name, key):
     (i) Their (phi, cc, sw) -> Lambda, Mu, Den maps on HIP tensors against the golden vectors generated by importing the
     reference's fwi_utils.py (tests/golden/rock_physics.npz), float32 accuracy.  (ii) A whole iteration -- module ->
     FWIFunction -> HIP propagator -> autograd chain rule -- on HIP tensors against the same chain on the reference's CPU
-    tensors: misfit within 1e-5; d/d(phi, cc, sw) of both against the float64 chain rule (<= 5e-4).  They stay torch expressions (about 40 elementwise kernels): the
-    1-GPU end-to-end run (profiles/r03_e2e_1gpu.log) puts the whole parameterisation chain at 0.2 % of an evaluation."""
+    tensors: misfit within 1e-5; d/d(phi, cc, sw) of both against the float64 chain rule (<= 5e-4).  On HIP tensors the module runs the fused maps (kinds 5 / 6, one launch
+    each way; test_fused_rock_physics_maps_equal_torch_expressions compares them with the torch expressions)."""
     import os
     from conftest import GOLDEN
     from sepfwi import modules as M
@@ -175,7 +218,8 @@ def test_rock_physics_modules_on_hip_tensors(tmp_path, hip_ops, cls_name, key):
         assert dev["cuda"] <= 5e-4 and dev["cpu"] <= 5e-4, (cls_name, name, dev)
         # (the yardstick uses the CPU run's media, so "cpu" shows the chain rule's own rounding, ~1e-7; torch's GPU kernels
         # produce media that differ in the last bit, and the propagator's gradient answers a 1-ulp change of the medium with
-        # ~1e-5: measured 2.6e-5 (VRH) and 2e-4 (Gassmann) -- float32 conditioning of the problem, on either device)
+        # ~1e-5: measured 2.6e-5 (VRH) and 2e-4 (Gassmann) with torch's GPU expressions in round 3 -- float32 conditioning of the
+        # problem, on either device; since round 5 the "cuda" chain is the fused map of csrc/param_maps.hip, kinds 5 and 6)
 
 
 def test_elastic_propagator_equals_the_autograd_module(tmp_path, hip_ops):
