@@ -133,6 +133,9 @@ typedef struct sepfwi_stats {
     int n_c;                  /* computed cells per step (nz-nPad)*(nx)  [PML included]       */
     double probe_kernel_us;   /* option "probe">0: mean duration of the sampled k_bwd_b launches (HIP events) */
     long long probe_calls;    /* number of sampled launches                                     */
+    long long obs_device_bytes; /* observed-data store: gathers resident in HBM (part of device_bytes)            */
+    long long obs_host_bytes;   /* ... and in the pinned host tier (only with a budget, key / option "obs_cache_mb") */
+    long long obs_evictions;    /* gathers moved HBM -> host tier since the store was created                       */
 } sepfwi_stats;
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 

@@ -35,6 +35,10 @@ Params parse_params(const std::string &text) {
     p.data_dir_name = j.at("data_dir_name").as_string("data_dir_name");
     if (j.has("scratch_dir_name")) p.scratch_dir_name = j.at("scratch_dir_name").as_string("scratch_dir_name");
     if (j.has("obs_pack_fname")) p.obs_pack_fname = j.at("obs_pack_fname").as_string("obs_pack_fname");
+    if (j.has("obs_cache_mb")) {
+        p.obs_cache_mb = j.at("obs_cache_mb").as_int("obs_cache_mb");
+        if (p.obs_cache_mb < 0) throw std::runtime_error("parameter JSON: obs_cache_mb must be >= 0");
+    }
     if (j.has("if_win")) p.if_win = j.at("if_win").as_bool("if_win");
     if (j.has("if_src_update")) p.if_src_update = j.at("if_src_update").as_bool("if_src_update");
     if (j.has("if_cross_misfit")) p.if_cross_misfit = j.at("if_cross_misfit").as_bool("if_cross_misfit");

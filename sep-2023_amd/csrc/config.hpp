@@ -15,6 +15,9 @@ struct Params {
     // optional key "obs_pack_fname" (SURVEY.md 8f-2): ONE packed file of the survey's observed axial-strain gathers (layout:
     // sepfwi/utils.py pack_observed) instead of the reference's four files per shot (libCUFD.cu:216-223)
     std::string obs_pack_fname;
+    // optional key "obs_cache_mb": HBM budget [MB] of the session's observed-data store; the least recently used gathers beyond it
+    // wait in pinned host memory (obs_store.hpp).  0 / absent: no budget (option "obs_cache_mb" of sepfwi_set_option applies).
+    int obs_cache_mb = 0;
     // data-conditioning keys (dormant in the reference's driver, libCUFD.cu:353-457; live here, csrc/conditioning.hip)
     bool if_win = false, if_src_update = false, if_cross_misfit = false, has_filter = false;
     // optional key "conditioning": "live" (default) -- the four keys above switch their stage on; "reference" -- they are parsed

@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 
 #include <mutex>
+#include <stdexcept>
 #include <string>
 
 #include "device_common.hpp"
@@ -940,6 +941,7 @@ const OptField kOptFields[] = {
     {"batch_order", &KernelOptions::batch_order, 0, 1},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
+    {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
 };
 }  // namespace
 
@@ -1027,10 +1029,32 @@ void launch_stress_adj(hipStream_t st, const Grid &g0, const KernelOptions &o, F
     hipLaunchKernelGGL(k_stress_adj, field_grid(g), BLOCK, 0, st, g, adj, m, md, pc);
 }
 
+// The fused backward kernels (and every batched kernel) receive their arrays as bundles: base pointer + one stride, the C-PML
+// profiles as ONE block (six z profiles of nzc floats, then six x profiles of nx).  The session allocates them that way; a
+// caller that does not must hear about it here, not through a kernel reading the wrong array.
+static void check_bundles(const Grid &g, const Fields &f, const PmlMem &m, const Media &md, const PmlCoef &pc, const Fields &adj, const ImgAcc &acc) {
+    const ptrdiff_t n = f.vx - f.vz;
+    const bool fields_ok = f.szz - f.vx == n && f.sxx - f.szz == n && f.sxz - f.sxx == n;
+    const bool adj_ok = adj.vx - adj.vz == n && adj.szz - adj.vx == n && adj.sxx - adj.szz == n && adj.sxz - adj.sxx == n;
+    const bool mem_ok = m.dvz_dx - m.dvz_dz == n && m.dvx_dz - m.dvz_dx == n && m.dvx_dx - m.dvx_dz == n && m.dszz_dz - m.dvx_dx == n &&
+                        m.dsxz_dx - m.dszz_dz == n && m.dsxz_dz - m.dsxz_dx == n && m.dsxx_dx - m.dsxz_dz == n;
+    const bool media_ok = md.mu - md.lam == n && md.ave_mu - md.mu == n && md.byc_a - md.ave_mu == n && md.byc_b - md.byc_a == n && md.rho - md.byc_b == n;
+    const bool acc_ok = acc.mu - acc.lam == n && acc.xz - acc.mu == n && acc.a - acc.xz == n && acc.b - acc.a == n;
+    const ptrdiff_t z = g.nzc, x = g.nx;
+    const bool coef_ok = pc.b_z - pc.a_z == z && pc.rK_z - pc.b_z == z && pc.a_zh - pc.rK_z == z && pc.b_zh - pc.a_zh == z && pc.rK_zh - pc.b_zh == z &&
+                         pc.a_x - pc.rK_zh == z && pc.b_x - pc.a_x == x && pc.rK_x - pc.b_x == x && pc.a_xh - pc.rK_x == x && pc.b_xh - pc.a_xh == x &&
+                         pc.rK_xh - pc.b_xh == x;
+    if (!(n > 0 && fields_ok && adj_ok && mem_ok && media_ok && acc_ok && coef_ok))
+        throw std::logic_error("bundled kernel launch: arrays are not laid out as base + k * stride (fields " + std::to_string(fields_ok) + ", adjoint " +
+                               std::to_string(adj_ok) + ", memories " + std::to_string(mem_ok) + ", media " + std::to_string(media_ok) + ", accumulators " +
+                               std::to_string(acc_ok) + ", C-PML profiles " + std::to_string(coef_ok) + ")");
+}
+
 void launch_bwd_a(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
                   const float *frame_t, Fields adj, ImgAcc acc) {
     const Grid g = tiled(g0, o, 1);
-    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
+    check_bundles(g, f, m, md, pc, adj, acc);
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};
     auto k = (o.early & 1) ? k_bwd_a<true> : k_bwd_a<false>;
     hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
@@ -1039,7 +1063,8 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                   int z_src, int x_src, float src_amp, float src_rxz, float *stf_grad_it, Fields adj, ImgAcc acc, LineRec lr,
                   hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
-    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};  // pc.a_x == pc.a_z + 6*nzc (session.cpp)
+    check_bundles(g, f, m, md, pc, adj, acc);
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};
     auto k = (o.early & 2) ? k_bwd_b<true> : k_bwd_b<false>;
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
         hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
@@ -1063,6 +1088,14 @@ static inline Grid tiled_batch(const Grid &g0, const KernelOptions &o, int fly_b
     g.shot_fastest = o.batch_order;
     return g;
 }
+static void check_shared_bundles(const Grid &g, const Media &md, const PmlCoef &pc) {
+    const ptrdiff_t n = md.mu - md.lam, z = g.nzc, x = g.nx;
+    const bool media_ok = n > 0 && md.ave_mu - md.mu == n && md.byc_a - md.ave_mu == n && md.byc_b - md.byc_a == n && md.rho - md.byc_b == n;
+    const bool coef_ok = pc.b_z - pc.a_z == z && pc.rK_z - pc.b_z == z && pc.a_zh - pc.rK_z == z && pc.b_zh - pc.a_zh == z && pc.rK_zh - pc.b_zh == z &&
+                         pc.a_x - pc.rK_zh == z && pc.b_x - pc.a_x == x && pc.rK_x - pc.b_x == x && pc.a_xh - pc.rK_x == x && pc.b_xh - pc.a_xh == x &&
+                         pc.rK_xh - pc.b_xh == x;
+    if (!(media_ok && coef_ok)) throw std::logic_error("batched kernel launch: media or C-PML profiles are not laid out as one bundle");
+}
 static inline dim3 batch_grid(const Grid &g) {
     const int nblk = g.gx * g.gy * g.nb;
     return dim3(g.xcd_remap ? ((nblk + 7) / 8) * 8 : nblk);
@@ -1070,6 +1103,7 @@ static inline dim3 batch_grid(const Grid &g) {
 void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                              PmlCoef pc, size_t n, size_t data_len, int it, float src_scale, bool save) {
     const Grid g = tiled_batch(g0, o, 0, nb);
+    check_shared_bundles(g, md, pc);
     if (save)
         hipLaunchKernelGGL(k_stress_fwd_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
     else
@@ -1078,11 +1112,13 @@ void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions
 void launch_velocity_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                                PmlCoef pc, size_t n) {
     const Grid g = tiled_batch(g0, o, 0, nb);
+    check_shared_bundles(g, md, pc);
     hipLaunchKernelGGL(k_velocity_fwd_batch, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
 }
 void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it) {
     const Grid g = tiled_batch(g0, o, 1, nb);
+    check_shared_bundles(g, md, pc);
     if (o.early & 1)
         hipLaunchKernelGGL(k_bwd_a_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
     else
@@ -1091,6 +1127,7 @@ void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, 
 void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled_batch(g0, o, 1, nb);
+    check_shared_bundles(g, md, pc);
     auto k = (o.early & 2) ? k_bwd_b_batch<true> : k_bwd_b_batch<false>;
     if (ev_start)
         hipExtLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);

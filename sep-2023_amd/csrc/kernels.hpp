@@ -25,6 +25,7 @@ struct KernelOptions {
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
+    int obs_cache_mb = 0; // HBM budget [MB] of the observed-data store (0: unlimited; a parameter-file key of the same name wins)
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)
 };

@@ -19,40 +19,11 @@
 #include <stdexcept>
 
 #include "device_alloc.hpp"
+#include "hip_check.hpp"
+#include "host_checks.hpp"
 #include "kernels.hpp"
 
 namespace sepfwi {
-
-#define HIP_OK(call)                                                                                          \
-    do {                                                                                                      \
-        hipError_t e_ = (call);                                                                               \
-        if (e_ != hipSuccess)                                                                                 \
-            throw HipError(std::string("HIP error '") + hipGetErrorString(e_) + "' at " + __FILE__ + ":" +    \
-                           std::to_string(__LINE__) + " in " #call);                                          \
-    } while (0)
-
-static const char *kComp[4] = {"pr", "vx", "vz", "ett"};  // libCUFD.cu:216-223,755-769
-
-// ------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------
-// Device that owns `p`, or -1 for host memory.  A pointer on ANOTHER device than the session's (the single-process
-// ngpu > 1 path handing GPU-0 tensors to the session of GPU i) is staged like host memory: the kernels only ever touch
-// memory of their own device, peer access is never assumed.
-static int ptr_device(const void *p) {
-    if (!p) return -1;
-    hipPointerAttribute_t attr;
-    hipError_t e = hipPointerGetAttributes(&attr, p);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();  // clear: plain host memory is reported as an error on some ROCm versions
-        return -1;
-    }
-    return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? attr.device : -1;
-}
-
-static std::string shot_file(const Params &p, int comp, int id) {
-    return p.data_dir_name + "/Shot_" + kComp[comp] + std::to_string(id) + ".bin";
-}
 
 template <class T>
 T *Session::dalloc(size_t n) {
@@ -143,27 +114,11 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
                       dx_, dx_ + nx,  dx_ + 2 * nx,  dx_ + 3 * nx,  dx_ + 4 * nx,  dx_ + 5 * nx};
     }
 
-    // ---- receivers: flat cell index per shot ----
+    // ---- receivers: flat cell index per shot (validated against the grid: host_checks.cpp) ----
     {
         const int ns = (int)survey_.shots.size();
-        rec_off_.assign(ns + 1, 0);
-        for (int i = 0; i < ns; i++) rec_off_[i + 1] = rec_off_[i] + (survey_.shots[i].present ? survey_.shots[i].nrec : 0);
-        std::vector<int> idx((size_t)rec_off_[ns] + 1);
-        for (int i = 0; i < ns; i++) {
-            const Shot &sh = survey_.shots[i];
-            if (!sh.present) continue;
-            if (sh.z_src < 2 || sh.z_src > g.nzc - 3 || sh.x_src < 2 || sh.x_src > g.nx - 3)
-                throw std::runtime_error("survey: source of shot " + std::to_string(i) + " lies outside the computed grid");
-            const bool dir = !sh.sens.empty();  // directional channels reach one cell in every direction
-            for (int r = 0; r < sh.nrec; r++) {
-                // the axial-strain difference reaches one cell to the left (horizontal fibre) or up (vertical fibre)
-                if (sh.z_rec[r] < ((par.fiber || dir) ? 1 : 0) || sh.z_rec[r] >= g.nzc - (dir ? 1 : 0) ||
-                    sh.x_rec[r] < ((par.fiber && !dir) ? 0 : 1) || sh.x_rec[r] >= g.nx - (dir ? 1 : 0))
-                    throw std::runtime_error("survey: receiver " + std::to_string(r) + " of shot " + std::to_string(i) +
-                                             " lies outside the grid");
-                idx[(size_t)rec_off_[i] + r] = sh.z_rec[r] * g.pitch + sh.x_rec[r];
-            }
-        }
+        std::vector<int> idx;
+        receiver_cells(par_, survey_, g.nzc, g.nx, g.pitch, &rec_off_, &idx);
         rec_idx_ = dalloc<int>(idx.size());
         HIP_OK(hipMemcpy(rec_idx_, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
         bool any_sens = false;
@@ -207,6 +162,17 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         device_bytes_ += cond_->device_bytes();
     }
     HIP_OK(hipHostMalloc((void **)&h_io_, dlen * sizeof(float), hipHostMallocDefault));
+    {
+        ObservedStore::Host h;
+        h.gpu_id = gpu_id_;
+        h.par = &par_;
+        h.survey = &survey_;
+        h.xpose = xpose_;
+        h.h_io = h_io_;
+        h.cond_on = cond_on_;
+        h.condition = [this](hipStream_t st, float *gather, int shot_id, int nrec) { condition_gather(st, gather, shot_id, nrec); };
+        obs_.reset(new ObservedStore(h));
+    }
     // everything the constructor put on the null stream (fills, profile / receiver tables copied from pageable host memory) is
     // complete before any stream of a later call -- the session's own non-blocking ones or a caller's -- can touch it
     HIP_OK(hipDeviceSynchronize());
@@ -232,7 +198,7 @@ Session::~Session() {
         if (L.stream) (void)hipStreamDestroy(L.stream);
         if (L.join) (void)hipEventDestroy(L.join);
     }
-    for (auto &kv : obs_) (void)hipFree(kv.second.d_ett);
+    obs_.reset();
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
     if (stf_grad_) (void)hipFree(stf_grad_);
@@ -307,14 +273,10 @@ void Session::ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots) 
 void Session::drop_observed() {
     std::lock_guard<std::mutex> lock(mu_);
     (void)hipSetDevice(gpu_id_);
-    for (auto &kv : obs_) {
-        (void)hipFree(kv.second.d_ett);
-        device_bytes_ -= (long long)kv.second.bytes;
-    }
-    obs_.clear();
+    obs_->clear();
 }
 
-// Observed axial-strain gather of one shot, time-major in HBM; (re)loaded when the file changed.
+// Observed axial-strain gather of one shot handed over from memory ([nrec][nSteps], host or device pointer).
 void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) {
     std::lock_guard<std::mutex> lock(mu_);
     HIP_OK(hipSetDevice(gpu_id_));
@@ -322,148 +284,9 @@ void Session::set_observed(int shot_id, const float *ett, int nrec, int nSteps) 
         throw std::invalid_argument("set_observed: unknown shot id " + std::to_string(shot_id));
     if (!ett || nrec != survey_.shots[shot_id].nrec || nSteps != par_.nSteps)
         throw std::invalid_argument("set_observed: data must be [nrec][nSteps] of the survey / parameter file");
-    const size_t want = (size_t)nrec * (size_t)nSteps * sizeof(float);
-    ObsEntry e;
-    auto it = obs_.find(shot_id);
-    if (it != obs_.end()) {
-        e = it->second;
-        if (e.bytes != want) {
-            (void)hipFree(e.d_ett);
-            device_bytes_ -= (long long)e.bytes;
-            e.d_ett = nullptr;
-        }
-    }
-    if (nrec > 0 && !e.d_ett) {
-        HIP_OK(dev_malloc((void **)&e.d_ett, want));
-        device_bytes_ += (long long)want;
-    }
-    e.bytes = want;
-    e.from_memory = true;
-    if (nrec > 0) {
-        hipStream_t st = own_stream_;
-        order_after_null_stream(st);  // a HIP `ett` was produced on the caller's (default) stream
-        HIP_OK(hipMemcpyAsync(xpose_, ett, want, hipMemcpyDefault, st));
-        if (cond_on_) {  // kept conditioned and trace-major
-            condition_gather(st, xpose_, shot_id, nrec);
-            HIP_OK(hipMemcpyAsync(e.d_ett, xpose_, want, hipMemcpyDeviceToDevice, st));
-        } else {
-            launch_transpose(st, xpose_, e.d_ett, nrec, nSteps);  // [rec][it] -> [it][rec]
-        }
-        HIP_OK(hipStreamSynchronize(st));
-    }
-    obs_[shot_id] = e;
-}
-
-// Byte offset of a shot's gather in the packed observed-data file (sepfwi/utils.py pack_observed), or -1 when the pack does not
-// hold the shot.  The index is re-read when the file changes.
-long long Session::pack_offset(int shot_id, int nrec) {
-    struct stat sb;
-    if (stat(par_.obs_pack_fname.c_str(), &sb) != 0) throw IoError("cannot read packed observed data '" + par_.obs_pack_fname + "'");
-    const long long stamp = (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec;
-    if (stamp != pack_mtime_ns_ || (long long)sb.st_size != pack_size_) {
-        pack_index_.clear();
-        FILE *fp = fopen(par_.obs_pack_fname.c_str(), "rb");
-        if (!fp) throw IoError("cannot read packed observed data '" + par_.obs_pack_fname + "'");
-        char magic[8];
-        int32_t head[2] = {0, 0};
-        bool ok = fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, "SEPFWIP1", 8) == 0 && fread(head, 4, 2, fp) == 2 && head[0] >= 0;
-        if (ok && head[1] != par_.nSteps) {
-            fclose(fp);
-            throw IoError("packed observed data '" + par_.obs_pack_fname + "' was written for another nSteps");
-        }
-        const long long head_bytes = 16 + 16LL * head[0];  // magic + (count, nSteps) + count x (id, nrec, offset)
-        std::string bad;
-        for (int k = 0; ok && k < head[0]; k++) {
-            int32_t e[2];
-            int64_t off;
-            ok = fread(e, 4, 2, fp) == 2 && fread(&off, 8, 1, fp) == 1;
-            if (!ok) break;
-            // every entry is checked where it is read: a corrupt index must not look like "shot not in the pack" (silent fall-back to
-            // Shot_ett{id}.bin) or surface later as a short read on some other file
-            const long long want = (long long)e[1] * (long long)par_.nSteps * (long long)sizeof(float);
-            if (e[1] < 0 || off < head_bytes || off > (long long)sb.st_size || want > (long long)sb.st_size - off)
-                bad = "entry " + std::to_string(k) + " (shot " + std::to_string(e[0]) + ") points outside the file";
-            else if (pack_index_.count(e[0]))
-                bad = "shot " + std::to_string(e[0]) + " is listed twice";
-            if (!bad.empty()) break;
-            pack_index_[e[0]] = std::make_pair((long long)off, (int)e[1]);
-        }
-        if (!bad.empty()) {
-            fclose(fp);
-            pack_index_.clear();
-            throw IoError("packed observed data '" + par_.obs_pack_fname + "': " + bad);
-        }
-        fclose(fp);
-        if (!ok) throw IoError("'" + par_.obs_pack_fname + "' is not a packed observed-data file");
-        pack_mtime_ns_ = stamp;
-        pack_size_ = (long long)sb.st_size;
-    }
-    auto it = pack_index_.find(shot_id);
-    if (it == pack_index_.end()) return -1;
-    if (it->second.second != nrec) throw IoError("packed observed data: shot " + std::to_string(shot_id) + " has another channel count than the survey");
-    return it->second.first;
-}
-
-const float *Session::observed_ett(int shot_id, int nrec, hipStream_t st) {
-    if (nrec <= 0) return nullptr;  // nothing to compare against
-    {
-        auto im = obs_.find(shot_id);
-        if (im != obs_.end() && im->second.from_memory && im->second.bytes == (size_t)nrec * (size_t)par_.nSteps * sizeof(float))
-            return im->second.d_ett;  // handed over through sepfwi_set_observed
-    }
-    // where the gather lives: the survey's packed file when the parameter file names one and it holds this shot, else the
-    // shot's own Shot_ett{id}.bin (libCUFD.cu:216-223)
-    std::string fn = shot_file(par_, 3, shot_id);
-    long long file_off = 0;
-    const size_t want = (size_t)nrec * (size_t)par_.nSteps * sizeof(float);
-    if (!par_.obs_pack_fname.empty()) {
-        long long off = pack_offset(shot_id, nrec);
-        if (off >= 0) {
-            fn = par_.obs_pack_fname;
-            file_off = off;
-        }
-    }
-    struct stat sb;
-    if (stat(fn.c_str(), &sb) != 0) throw IoError("cannot read observed data '" + fn + "'");  // utilities.cu:12-16
-    if ((long long)sb.st_size < file_off + (long long)want) throw IoError("observed data '" + fn + "' is shorter than nrec*nSteps floats");
-    auto it = obs_.find(shot_id);
-    if (it != obs_.end() && it->second.mtime_ns == (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec &&
-        it->second.size == (long long)sb.st_size && it->second.bytes == want && !it->second.from_memory)
-        return it->second.d_ett;
-    FILE *fp = fopen(fn.c_str(), "rb");
-    if (!fp) throw IoError("cannot read observed data '" + fn + "'");
-    HIP_OK(hipStreamSynchronize(st));  // h_io_ / xpose_ may still be in use
-    size_t got = 0;
-    if (fseeko(fp, (off_t)file_off, SEEK_SET) == 0) got = fread(h_io_, 1, want, fp);
-    fclose(fp);
-    if (got != want) throw IoError("short read on '" + fn + "'");
-    ObsEntry e;
-    if (it != obs_.end()) {
-        e = it->second;
-        if (e.bytes != want) {
-            (void)hipFree(e.d_ett);
-            device_bytes_ -= (long long)e.bytes;
-            e.d_ett = nullptr;
-        }
-    }
-    if (!e.d_ett) {
-        HIP_OK(dev_malloc((void **)&e.d_ett, want));
-        device_bytes_ += (long long)want;
-    }
-    e.bytes = want;
-    e.from_memory = false;
-    e.size = (long long)sb.st_size;
-    e.mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec;
-    HIP_OK(hipMemcpyAsync(xpose_, h_io_, want, hipMemcpyHostToDevice, st));
-    if (cond_on_) {  // kept conditioned and trace-major
-        condition_gather(st, xpose_, shot_id, nrec);
-        HIP_OK(hipMemcpyAsync(e.d_ett, xpose_, want, hipMemcpyDeviceToDevice, st));
-    } else {
-        launch_transpose(st, xpose_, e.d_ett, nrec, par_.nSteps);  // [rec][it] -> [it][rec]
-    }
-    HIP_OK(hipStreamSynchronize(st));
-    obs_[shot_id] = e;
-    return e.d_ett;
+    if (nrec > 0) order_after_null_stream(own_stream_);  // a HIP `ett` was produced on the caller's (default) stream
+    obs_->release_all();
+    obs_->put(shot_id, ett, nrec, own_stream_);
 }
 
 // Window and band-pass one [rec][it] gather in place, as the commented driver lines apply them to observed and synthetic
@@ -476,596 +299,6 @@ void Session::condition_gather(hipStream_t st, float *gather, int shot_id, int n
     else
         cond_->window(st, gather, nrec, par_.dt, nullptr, nullptr, nullptr, 1.0f, 0.005f);
     if (par_.has_filter) cond_->bandpass(st, gather, nrec, par_.dt, par_.filter);
-}
-
-// ------------------------------------------------------------------------------------------------
-// the cufd call
-// ------------------------------------------------------------------------------------------------
-// A NULL stream argument means the legacy default stream, which is what torch's default stream is on ROCm: the call's
-// own (non-blocking) stream must not start before the work already queued there -- the Lame maps that produced
-// Lambda/Mu/Den, the zero-fill of the gradient tensors -- has finished.
-void Session::order_after_null_stream(hipStream_t st) {
-    HIP_OK(hipEventRecord(ev_order_, nullptr));
-    HIP_OK(hipStreamWaitEvent(st, ev_order_, 0));
-}
-
-void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf,
-                  const float *Lambda, const float *Mu, const float *Den, const float *stf, int calc_id,
-                  int group_size, const int *shot_ids, hipStream_t ext_stream, bool async) {
-    std::lock_guard<std::mutex> lock(mu_);
-    const auto t_begin = std::chrono::steady_clock::now();
-    HIP_OK(hipSetDevice(gpu_id_));
-    const KernelOptions opt = kernel_options();  // ONE snapshot for the whole call
-    hipStream_t st = ext_stream ? ext_stream : own_stream_;
-    if (!ext_stream) order_after_null_stream(st);
-    const Grid &g = g_;
-    const bool if_res = (calc_id == 0 || calc_id == 1);  // Parameter.cpp:125-137
-    const bool withAdj = (calc_id == 1);
-    const bool to_store = (calc_id == SEPFWI_CALC_OBSERVE_TO_STORE);  // observe, but into the HBM store instead of the four files
-    const int nSteps = par_.nSteps;
-    const size_t n = cells_;
-    const size_t dense = (size_t)par_.nz * (size_t)par_.nx;
-    launches_ = 0;
-
-    for (int i = 0; i < group_size; i++) {
-        const int id = shot_ids[i];
-        if (id < 0 || id >= (int)survey_.shots.size() || !survey_.shots[id].present)
-            throw std::invalid_argument("shot id " + std::to_string(id) + " is not in the survey file");
-    }
-
-    // ---- media: boundary arrays -> internal layout, averages, Courant guard ----
-    // inputs that do not live on this session's device (host memory, or another GPU's memory) are staged
-    const float *dL = Lambda, *dM = Mu, *dD = Den;
-    if (ptr_device(Lambda) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_, Lambda, dense * sizeof(float), hipMemcpyDefault, st)); dL = in_stage_; }
-    if (ptr_device(Mu) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_ + dense, Mu, dense * sizeof(float), hipMemcpyDefault, st)); dM = in_stage_ + dense; }
-    if (ptr_device(Den) != gpu_id_) { HIP_OK(hipMemcpyAsync(in_stage_ + 2 * dense, Den, dense * sizeof(float), hipMemcpyDefault, st)); dD = in_stage_ + 2 * dense; }
-    HIP_OK(hipMemsetAsync(cp2_bits_, 0, sizeof(unsigned int), st));
-    launch_model_prep(st, g, opt, dL, dM, dD, media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n, cp2_bits_);
-    launches_++;
-    {
-        unsigned int bits = 0;
-        HIP_OK(hipMemcpyAsync(&bits, cp2_bits_, sizeof(bits), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        float cp2;
-        std::memcpy(&cp2, &bits, sizeof(cp2));
-        const float vmax = (float)std::sqrt((double)cp2);
-        const float dh_min = (par_.dz < par_.dx) ? par_.dz : par_.dx;
-        const float courant = (float)((double)(vmax * par_.dt * sqrtf(2.0f)) * (1.0 / 24.0 + 9.0 / 8.0) / (double)dh_min);
-        if (!(courant <= 1.0f)) throw CourantError("Courant number " + std::to_string(courant) + " > 1 (vmax " + std::to_string(vmax) + " m/s)");
-    }
-
-    // ---- boundary-saving storage (Boundary.cu:29-41), allocated on first gradient call ----
-    if (withAdj && !frame_) {
-        const size_t fb = (size_t)nSteps * 5 * (size_t)g.frame_len * sizeof(float);
-        HIP_OK(dev_malloc((void **)&frame_, fb));
-        device_bytes_ += (long long)fb;
-    }
-    if (withAdj) HIP_OK(hipMemsetAsync(acc_buf_, 0, 5 * n * sizeof(float), st));  // Model.cu:68-71
-    if (if_res) HIP_OK(hipMemsetAsync(scal_, 0, 4 * sizeof(double), st));
-
-    // ---- source traces on the host: row shot_ids[i] of stf, tapered (Src_Rec.cu:130-137) ----
-    std::vector<float> stf_rows((size_t)group_size * nSteps);
-    for (int i = 0; i < group_size; i++) {
-        HIP_OK(hipMemcpy(stf_rows.data() + (size_t)i * nSteps, stf + (size_t)shot_ids[i] * nSteps, nSteps * sizeof(float),
-                         hipMemcpyDefault));
-        stf_taper(stf_rows.data() + (size_t)i * nSteps, nSteps, par_.dt, 0.001f);
-    }
-    const float src_scale = (float)std::pow(1500.0, 2);  // utilities.cu:531
-
-    fwd_ms_ = bwd_ms_ = 0.0;
-    probe_us_ = 0.0;
-    probe_calls_ = 0;
-    fwd_steps_ = bwd_steps_ = 0;
-    std::vector<float> h_gstf;
-
-    // Per-shot context.  Several "lanes" of forward state exist so that the forward passes of several shots can run
-    // concurrently on their own streams (their kernel-boundary gaps and tails fill each other: x1.28 on the forward
-    // loops with three lanes); the backward passes then run one after the other -- two of them together do not fit the
-    // 256 MB Infinity Cache and lose 15 % (scripts/concurrency_probe.py).
-    struct ShotCtx {
-        int is, id, nrec, comps;
-        const Shot *sh;
-        const int *rec;
-        const float *stf_s, *d_obs;
-        const float *sens;  // directional sensitivities of this shot's channels (device) or null
-        bool scratch;
-        LineRec line;
-        float *state;  // [5 fields | 8 memory variables] of this lane
-        Fields fld;
-        PmlMem mem;
-        float *frame, *syn, *res;
-        hipStream_t st;
-    };
-    if (withAdj) {  // source-time-function gradients of all shots of the call, one row each
-        const size_t need = (size_t)group_size * nSteps;
-        if (need > stf_grad_len_) {
-            if (stf_grad_) (void)hipFree(stf_grad_);
-            stf_grad_ = nullptr;
-            HIP_OK(dev_malloc((void **)&stf_grad_, need * sizeof(float)));
-            device_bytes_ += (long long)((need - stf_grad_len_) * sizeof(float));
-            stf_grad_len_ = need;
-        }
-        HIP_OK(hipMemsetAsync(stf_grad_, 0, need * sizeof(float), st));
-    }
-    if (if_res)  // observed data of every shot of the call resident before the time loops start
-        for (int is = 0; is < group_size; is++) (void)observed_ett(shot_ids[is], survey_.shots[shot_ids[is]].nrec, st);
-    int n_lanes = opt.pair_fwd ? opt.fwd_lanes : 1;  // concurrent forward passes
-    if (n_lanes > group_size) n_lanes = group_size;
-    if (n_lanes > kMaxLanes) n_lanes = kMaxLanes;
-    if (n_lanes < 1) n_lanes = 1;
-
-    auto make_ctx = [&](int is, int lane, hipStream_t lane_st) -> ShotCtx {
-        ShotCtx c{};
-        c.is = is;
-        c.id = shot_ids[is];
-        c.sh = &survey_.shots[c.id];
-        c.nrec = c.sh->nrec;
-        c.rec = rec_idx_ + rec_off_[c.id];
-        c.sens = (sens_ && !c.sh->sens.empty()) ? sens_ + 3 * (size_t)rec_off_[c.id] : nullptr;
-        c.stf_s = stf_rows.data() + (size_t)is * nSteps;
-        c.d_obs = if_res ? observed_ett(c.id, c.nrec, st) : nullptr;
-        c.scratch = withAdj && !par_.scratch_dir_name.empty();  // libCUFD.cu:732-752
-        c.comps = (if_res || to_store) ? (c.scratch ? 9 : 8) : 15;
-        // horizontal line of consecutive channels inside the computed region?
-        const Shot &sh = *c.sh;
-        bool is_line = par_.fiber == 0 && !c.sens && c.nrec > 0 && sh.z_rec[0] >= 2 && sh.z_rec[0] <= g.nzc - 3 && sh.x_rec[0] >= 3 && sh.x_rec[0] + c.nrec - 1 <= g.nx - 3;
-        for (int r = 1; r < c.nrec && is_line; r++) is_line = (sh.z_rec[r] == sh.z_rec[0] && sh.x_rec[r] == sh.x_rec[0] + r);
-        if (is_line) {
-            c.line.z = sh.z_rec[0];
-            c.line.x0 = sh.x_rec[0];
-            c.line.n = c.nrec;
-        }
-        c.state = lane ? xl_[lane].state : state_;
-        float *b = c.state;
-        c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
-        c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
-        c.frame = lane ? xl_[lane].frame : frame_;
-        c.syn = lane ? xl_[lane].syn : syn_;
-        c.res = lane ? xl_[lane].res : res_;
-        c.st = lane_st;
-        return c;
-    };
-    auto syn_of = [&](const ShotCtx &c, int comp) { return c.syn + (size_t)comp * data_len_; };
-
-    auto forward_init = [&](const ShotCtx &c) {
-        // zero the 5 fields + 8 memory variables (libCUFD.cu:175-194); data column 0 stays 0 (:205-209)
-        HIP_OK(hipMemsetAsync(c.state, 0, 13 * n * sizeof(float), c.st));
-        for (int k = 0; k < 4; k++)
-            if ((c.comps >> k) & 1) HIP_OK(hipMemsetAsync(syn_of(c, k), 0, (size_t)c.nrec * sizeof(float), c.st));
-    };
-    // one forward time step (libCUFD.cu:268-332)
-    auto forward_step = [&](const ShotCtx &c, int it, bool inl) {
-        float *frame_t = withAdj ? c.frame + (size_t)it * 5 * (size_t)g.frame_len : nullptr;
-        const float amp = src_scale * c.stf_s[it] * par_.dt;
-        LineRec lr{};
-        if (inl && it >= 1) {
-            lr = c.line;
-            const size_t c0 = (size_t)it * c.nrec;
-            lr.d_vx = (c.comps & 2) ? syn_of(c, 1) + c0 : nullptr;
-            lr.d_vz = (c.comps & 4) ? syn_of(c, 2) + c0 : nullptr;
-            lr.d_ett = (c.comps & 8) ? syn_of(c, 3) + c0 : nullptr;
-        }
-        launch_stress_fwd(c.st, g, opt, c.fld, c.mem, md_, pc_, frame_t, c.sh->z_src, c.sh->x_src, amp, lr);
-        launch_velocity_fwd(c.st, g, opt, c.fld, c.mem, md_, pc_);
-        launches_ += 2;
-        if (!inl) {
-            const size_t col = (size_t)(it + 1) * c.nrec;
-            launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
-            launches_++;
-        }
-    };
-    auto forward_last_column = [&](const ShotCtx &c) {
-        const size_t col = (size_t)(nSteps - 1) * c.nrec;
-        launch_record(c.st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
-        launches_++;
-    };
-    auto residual = [&](const ShotCtx &c) {
-        // residual + misfit of the axial-strain component (libCUFD.cu:413,418,427)
-        launch_residual(c.st, c.d_obs, syn_of(c, 3), c.res, c.nrec, (long long)c.nrec * nSteps, scal_);
-        launches_++;
-    };
-    // the same with the data-conditioning chain (libCUFD.cu:353-457 as its commented lines compose it), on the MAIN stream:
-    // the scratch gathers and the FFT work space are shared by the shots of a call
-    auto residual_conditioned = [&](const ShotCtx &c) {
-        if (c.nrec <= 0) return;
-        const size_t tot = (size_t)rec_off_.back() + 1, off = (size_t)rec_off_[c.id];
-        launch_transpose(st, syn_of(c, 3), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
-        condition_gather(st, xpose_, c.id, c.nrec);
-        if (par_.if_src_update) cond_->source_update(st, c.d_obs, xpose_, c.nrec, par_.dt);   // libCUFD.cu:383-390
-        if (par_.if_cross_misfit)
-            cond_->cross_residual(st, c.d_obs, xpose_, xpose2_, c.nrec, win_ + 2 * tot + off, c.sh->src_weight, scal_);
-        else
-            cond_->l2_residual(st, c.d_obs, xpose_, xpose2_, c.nrec, scal_);
-        if (par_.if_src_update) cond_->source_update_adj(st, xpose2_, c.nrec, par_.dt);       // libCUFD.cu:430-433
-        if (par_.has_filter) cond_->bandpass(st, xpose2_, c.nrec, par_.dt, par_.filter);  // adjoint of the (zero-phase) filter
-        if (par_.if_win)
-            cond_->window(st, xpose2_, c.nrec, par_.dt, win_ + off, win_ + tot + off, win_ + 2 * tot + off, c.sh->src_weight, 0.005f);
-        else
-            cond_->window(st, xpose2_, c.nrec, par_.dt, nullptr, nullptr, nullptr, 1.0f, 0.005f);
-        launch_transpose(st, xpose2_, c.res, c.nrec, nSteps);  // [rec][it] -> [it][rec]: the adjoint source
-        launches_ += 8;
-    };
-    auto export_gathers = [&](const ShotCtx &c) {
-        // observe: export the four gathers as [nrec][nSteps] files (libCUFD.cu:755-769)
-        for (int k = 0; k < 4; k++) {
-            launch_transpose(st, syn_of(c, k), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
-            HIP_OK(hipMemcpyAsync(h_io_, xpose_, (size_t)c.nrec * nSteps * sizeof(float), hipMemcpyDeviceToHost, st));
-            HIP_OK(hipStreamSynchronize(st));
-            const std::string fn = shot_file(par_, k, c.id);
-            FILE *fp = fopen(fn.c_str(), "wb");
-            if (!fp) throw IoError("cannot write '" + fn + "'");  // utilities.cu:22-31
-            size_t w = fwrite(h_io_, sizeof(float), (size_t)c.nrec * nSteps, fp);
-            fclose(fp);
-            if (w != (size_t)c.nrec * nSteps) throw IoError("short write on '" + fn + "'");
-        }
-        auto oit = obs_.find(c.id);  // stale cache entry for this shot: drop, the file just changed
-        if (oit != obs_.end()) {
-            (void)hipFree(oit->second.d_ett);
-            device_bytes_ -= (long long)oit->second.bytes;
-            obs_.erase(oit);
-        }
-    };
-    // observe into the store (calc_id 3): the modelled axial-strain gather becomes the shot's observed data exactly as
-    // sepfwi_set_observed would install the Shot_ett file of calc_id 2 -- the device gather is already in the store's time-major layout
-    auto store_gather = [&](const ShotCtx &c) {
-        const size_t want = (size_t)c.nrec * (size_t)nSteps * sizeof(float);
-        ObsEntry e;
-        auto oit = obs_.find(c.id);
-        if (oit != obs_.end()) {
-            e = oit->second;
-            if (e.bytes != want) {
-                (void)hipFree(e.d_ett);
-                device_bytes_ -= (long long)e.bytes;
-                e.d_ett = nullptr;
-            }
-        }
-        if (c.nrec > 0 && !e.d_ett) {
-            HIP_OK(dev_malloc((void **)&e.d_ett, want));
-            device_bytes_ += (long long)want;
-        }
-        e.bytes = want;
-        e.from_memory = true;
-        if (c.nrec > 0) {
-            if (cond_on_) {  // kept conditioned and trace-major
-                launch_transpose(st, syn_of(c, 3), xpose_, nSteps, c.nrec);  // [it][rec] -> [rec][it]
-                condition_gather(st, xpose_, c.id, c.nrec);
-                HIP_OK(hipMemcpyAsync(e.d_ett, xpose_, want, hipMemcpyDeviceToDevice, st));
-            } else {
-                HIP_OK(hipMemcpyAsync(e.d_ett, syn_of(c, 3), want, hipMemcpyDeviceToDevice, st));
-            }
-            HIP_OK(hipStreamSynchronize(st));
-        }
-        obs_[c.id] = e;
-    };
-    auto scratch_dumps = [&](const ShotCtx &c) {
-        // optional scratch dumps of the PRESSURE component, [nrec][nSteps] float32 (libCUFD.cu:732-745):
-        // Syn_Shot{id}.bin, CondObs_Shot{id}.bin (observed data, unconditioned here as there) and
-        // Residual_Shot{id}.bin = obs - syn with the first time sample zeroed (gpuMinus, utilities.cu:154-167)
-        const size_t cnt = (size_t)c.nrec * nSteps;
-        launch_transpose(st, syn_of(c, 0), xpose_, nSteps, c.nrec);
-        HIP_OK(hipMemcpyAsync(h_io_, xpose_, cnt * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        std::vector<float> obs_pr(cnt);
-        {
-            const std::string fn = shot_file(par_, 0, c.id);
-            FILE *fp = fopen(fn.c_str(), "rb");
-            if (!fp) throw IoError("cannot read observed data '" + fn + "'");
-            const size_t got = fread(obs_pr.data(), sizeof(float), cnt, fp);
-            fclose(fp);
-            if (got != cnt) throw IoError("short read on '" + fn + "'");
-        }
-        auto dump = [&](const char *stem, const float *data) {
-            const std::string fn = par_.scratch_dir_name + "/" + stem + std::to_string(c.id) + ".bin";
-            FILE *fp = fopen(fn.c_str(), "wb");
-            if (!fp) throw IoError("cannot write '" + fn + "'");
-            const size_t w = fwrite(data, sizeof(float), cnt, fp);
-            fclose(fp);
-            if (w != cnt) throw IoError("short write on '" + fn + "'");
-        };
-        dump("Syn_Shot", h_io_);
-        dump("CondObs_Shot", obs_pr.data());
-        for (int r = 0; r < c.nrec; r++) {
-            float *o = obs_pr.data() + (size_t)r * nSteps;
-            const float *sy = h_io_ + (size_t)r * nSteps;
-            o[0] = 0.0f;
-            for (int t = 1; t < nSteps; t++) o[t] = o[t] - sy[t];
-        }
-        dump("Residual_Shot", obs_pr.data());
-    };
-    // ---------------- backward of one shot (libCUFD.cu:500-675) ----------------
-    // A backward lane = stream + backward-pass memory variables + adjoint fields + imaging accumulators.
-    struct BwdLane {
-        hipStream_t s;
-        PmlMem bm;
-        Fields adj;
-        ImgAcc acc;
-    };
-    const int fuse_bwd = opt.bwd_fuse;
-    const int probe = opt.probe;
-    int n_probe = 0;
-    auto backward_init = [&](const BwdLane &L) {
-        // adjoint fields + all eight memory variables restart from zero (:503-515); the two pre-loop
-        // adjoint launches (:520-542) act on all-zero arrays and change nothing.
-        HIP_OK(hipMemsetAsync(L.bm.dvz_dz, 0, 8 * n * sizeof(float), L.s));
-        HIP_OK(hipMemsetAsync(L.adj.vz, 0, 5 * n * sizeof(float), L.s));
-    };
-    auto backward_step = [&](const ShotCtx &c, const BwdLane &L, int it) {
-        const bool inj_inl = c.line.n > 0 && opt.line_fuse != 0;
-        const Shot &sh = *c.sh;
-        float *frame_t = c.frame + (size_t)it * 5 * (size_t)g.frame_len;
-        float *sg = stf_grad_ + (size_t)c.is * nSteps + it;
-        const float amp = src_scale * c.stf_s[it] * par_.dt;
-        const float *res_t = c.res + (size_t)it * c.nrec;
-        LineRec lr{};
-        if (inj_inl) {
-            lr = c.line;
-            lr.res = res_t;
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0 && fuse_bwd != 0) {
-            e0 = probe_ev_[2 * n_probe];
-            e1 = probe_ev_[2 * n_probe + 1];
-            n_probe++;
-        }
-        Grid gs = g;  // this step's imaging weight (option img_every)
-        if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-        if (fuse_bwd == 2) {
-            launch_bwd_a(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
-            launch_bwd_b(L.s, gs, opt, c.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, e0, e1);
-            if (!inj_inl) launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
-            launches_ += inj_inl ? 2 : 3;
-        } else {  // the reference's launch structure
-            launch_velocity_rev(L.s, gs, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, (float)sh.src_rxz, sg, L.adj, L.acc);
-            launch_stress_rev(L.s, gs, opt, c.fld, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, L.adj, L.acc);
-            launch_velocity_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
-            launch_inject(L.s, g, L.adj, c.nrec, c.rec, res_t, c.sens);
-            launch_stress_adj(L.s, g, opt, L.adj, L.bm, md_, pc_);
-            launches_ += 5;
-        }
-    };
-    auto collect_probes = [&]() {  // after a synchronisation of the main stream
-        for (int k = 0; k < n_probe; k++) {
-            float ms = 0.f;
-            HIP_OK(hipEventElapsedTime(&ms, probe_ev_[2 * k], probe_ev_[2 * k + 1]));
-            probe_us_ += 1e3 * ms;
-            probe_calls_++;
-        }
-        n_probe = 0;
-    };
-    auto backward = [&](const ShotCtx &c) {
-        const BwdLane L{st, mem_, adj_, acc_};
-        HIP_OK(hipEventRecord(ev_[2], st));
-        backward_init(L);
-        for (int it = nSteps - 2; it >= 0; it--) backward_step(c, L, it);
-        HIP_OK(hipEventRecord(ev_[3], st));
-        bwd_steps_ += (long long)(nSteps - 1);
-        HIP_OK(hipStreamSynchronize(st));
-        collect_probes();
-        float ms = 0.f;
-        HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
-        bwd_ms_ += ms;
-    };
-    auto forward_inline = [&](const ShotCtx &c) { return c.line.n > 0 && !(c.comps & 1) && opt.line_fuse != 0; };
-
-    // ---------------- batched mode: every launch advances a whole batch of shots ----------------
-    // Batch sizes from the Infinity-Cache budget: a forward batch keeps 5 fields per shot + 5 media arrays resident, a
-    // backward batch 15 arrays per shot + 5 (2000x500: 7 and 2; a 101x201 notebook problem: all its shots at once).  Where
-    // not even two backward passes fit (2000x1000) the stream mode below runs the backward passes one by one.
-    const double arr_mb = (double)n * sizeof(float) / 1.0e6, budget = (double)opt.batch_mb;
-    int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
-    const bool batched = fuse_bwd == 2 && group_size >= 1 &&
-                         (opt.batch == 1 || (opt.batch == 2 && (withAdj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
-    last_batched_ = batched;
-    if (batched) {
-        if (opt.batch_f > 0) Bf = opt.batch_f;
-        if (opt.batch_b > 0) Bb = opt.batch_b;
-        Bf = std::max(1, std::min(std::min(Bf, 32), group_size));
-        Bb = std::max(1, std::min(Bb, Bf));
-        if (!opt.pair_fwd) Bf = Bb = 1;
-        ensure_batch(Bf, withAdj ? Bb : 0, withAdj, group_size);
-        HIP_OK(hipMemcpyAsync(d_stf_, stf_rows.data(), (size_t)group_size * nSteps * sizeof(float), hipMemcpyHostToDevice, st));
-        const bool lf = opt.line_fuse != 0;
-        auto lane_ctx = [&](int is) {  // shot `is` of the call in its batch lane
-            ShotCtx c = make_ctx(is, 0, st);
-            const BLane &L = bl_[is % Bf];
-            c.state = L.state;
-            float *b = c.state;
-            c.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
-            c.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
-            c.frame = L.frame;
-            c.syn = L.syn;
-            c.res = L.res;
-            return c;
-        };
-        std::vector<ShotDev> tab(group_size);
-        for (int is = 0; is < group_size; is++) {
-            const ShotCtx c = lane_ctx(is);
-            const BLane &LB = bl_[(is % Bf) % Bb];  // backward lane of this shot inside its sub-batch
-            ShotDev &d = tab[is];
-            d.fields = c.state;
-            d.mem = c.state + 5 * n;
-            d.frame = c.frame;
-            d.syn = c.syn;
-            d.stf = d_stf_ + (size_t)is * nSteps;
-            d.bmem = withAdj ? LB.bwd : nullptr;
-            d.adj = withAdj ? LB.bwd + 8 * n : nullptr;
-            d.acc = withAdj ? LB.bwd + 13 * n : nullptr;
-            d.res = c.res;
-            d.stf_grad = withAdj ? stf_grad_ + (size_t)is * nSteps : nullptr;
-            d.z_src = c.sh->z_src;
-            d.x_src = c.sh->x_src;
-            d.lr_z = c.line.z;
-            d.lr_x0 = c.line.x0;
-            d.lr_n = lf ? c.line.n : 0;
-            d.comps = c.comps | ((lf && c.line.n > 0 && !(c.comps & 1)) ? 16 : 0);  // bit 16: sample the line inside k_stress
-            d.nrec = c.nrec;
-            d.src_rxz = (float)c.sh->src_rxz;
-        }
-        HIP_OK(hipMemcpyAsync(d_shots_, tab.data(), tab.size() * sizeof(ShotDev), hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));  // `tab` and `stf_rows` are pageable host memory
-        if (withAdj)
-            for (int k = 0; k < Bb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd + 13 * n, 0, 5 * n * sizeof(float), st));
-
-        for (int is0 = 0; is0 < group_size; is0 += Bf) {
-            const int nb = std::min(Bf, group_size - is0);
-            std::vector<ShotCtx> cx;
-            for (int k = 0; k < nb; k++) cx.push_back(lane_ctx(is0 + k));
-            // ---- forward time loop, libCUFD.cu:268-332
-            HIP_OK(hipEventRecord(ev_[0], st));
-            for (int k = 0; k < nb; k++) forward_init(cx[k]);
-            for (int it = 0; it <= nSteps - 2; it++) {
-                launch_stress_fwd_batch(st, g, opt, d_shots_ + is0, nb, md_, pc_, n, data_len_, it, src_scale, withAdj);
-                launch_velocity_fwd_batch(st, g, opt, d_shots_ + is0, nb, md_, pc_, n);
-                launches_ += 2;
-                for (int k = 0; k < nb; k++)
-                    if (!(tab[is0 + k].comps & 16)) {  // general receivers: sample the new state into column it+1
-                        const ShotCtx &c = cx[k];
-                        const size_t col = (size_t)(it + 1) * c.nrec;
-                        launch_record(st, g, c.fld, c.nrec, c.rec, syn_of(c, 0) + col, syn_of(c, 1) + col, syn_of(c, 2) + col, syn_of(c, 3) + col, c.comps, c.sens);
-                        launches_++;
-                    }
-            }
-            for (int k = 0; k < nb; k++)
-                if (tab[is0 + k].comps & 16) forward_last_column(cx[k]);
-            if (if_res)
-                for (int k = 0; k < nb; k++) cond_on_ ? residual_conditioned(cx[k]) : residual(cx[k]);
-            HIP_OK(hipEventRecord(ev_[1], st));
-            fwd_steps_ += (long long)nb * (nSteps - 1);
-            HIP_OK(hipStreamSynchronize(st));
-            {
-                float ms = 0.f;
-                HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-                fwd_ms_ += ms;
-            }
-            for (int k = 0; k < nb; k++) {
-                if (to_store) {
-                    store_gather(cx[k]);
-                } else if (!if_res) {
-                    export_gathers(cx[k]);
-                } else if (cx[k].scratch) {
-                    scratch_dumps(cx[k]);
-                }
-            }
-            // ---- backward time loops in sub-batches, libCUFD.cu:500-675
-            for (int kb = 0; withAdj && kb < nb; kb += Bb) {
-                const int nbb = std::min(Bb, nb - kb);
-                HIP_OK(hipEventRecord(ev_[2], st));
-                for (int k = 0; k < nbb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd, 0, 13 * n * sizeof(float), st));  // memories + adjoint fields
-                for (int it = nSteps - 2; it >= 0; it--) {
-                    hipEvent_t e0 = nullptr, e1 = nullptr;
-                    if (probe > 0 && n_probe < kProbePairs && (it % probe) == 0) {
-                        e0 = probe_ev_[2 * n_probe];
-                        e1 = probe_ev_[2 * n_probe + 1];
-                        n_probe++;
-                    }
-                    Grid gs = g;
-                    if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-                    launch_bwd_a_batch(st, gs, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
-                    launch_bwd_b_batch(st, gs, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, src_scale, e0, e1);
-                    launches_ += 2;
-                    for (int k = 0; k < nbb; k++)
-                        if (tab[is0 + kb + k].lr_n == 0) {
-                            const ShotCtx &c = cx[kb + k];
-                            const Fields adj = Fields{bl_[k].bwd + 8 * n, bl_[k].bwd + 9 * n, bl_[k].bwd + 10 * n, bl_[k].bwd + 11 * n, bl_[k].bwd + 12 * n};
-                            launch_inject(st, g, adj, c.nrec, c.rec, c.res + (size_t)it * c.nrec, c.sens);
-                            launches_++;
-                        }
-                }
-                HIP_OK(hipEventRecord(ev_[3], st));
-                bwd_steps_ += (long long)nbb * (nSteps - 1);
-                HIP_OK(hipStreamSynchronize(st));
-                collect_probes();
-                float ms = 0.f;
-                HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
-                bwd_ms_ += ms;
-            }
-        }
-        if (withAdj)  // the batch lanes' accumulators -> the session's (zeroed above), summed in lane order
-            for (int k = 0; k < Bb; k++) {
-                launch_add_inplace(st, acc_.lam, bl_[k].bwd + 13 * n, 5 * n);
-                launches_++;
-            }
-    }
-    // ---------------- stream mode: up to fwd_lanes forward passes side by side, then their backward passes ----------------
-    if (!batched && n_lanes >= 2) ensure_lanes(n_lanes, withAdj);
-    for (int is = 0; is < group_size && !batched;) {
-        const int np = std::min(n_lanes, group_size - is);
-        ShotCtx ctx[kMaxLanes];
-        ctx[0] = make_ctx(is, 0, st);
-        for (int k = 1; k < np; k++) ctx[k] = make_ctx(is + k, k, xl_[k].stream);
-
-        // forward time loop(s), libCUFD.cu:268-332
-        HIP_OK(hipEventRecord(ev_[0], st));
-        for (int k = 1; k < np; k++) HIP_OK(hipStreamWaitEvent(xl_[k].stream, ev_[0], 0));  // extra lanes start after everything queued so far
-        for (int k = 0; k < np; k++) forward_init(ctx[k]);
-        bool inl[kMaxLanes];
-        for (int k = 0; k < np; k++) inl[k] = forward_inline(ctx[k]);
-        for (int it = 0; it <= nSteps - 2; it++)
-            for (int k = 0; k < np; k++) forward_step(ctx[k], it, inl[k]);
-        for (int k = 0; k < np; k++)
-            if (inl[k]) forward_last_column(ctx[k]);
-        if (if_res && !cond_on_)
-            for (int k = 0; k < np; k++) residual(ctx[k]);
-        for (int k = 1; k < np; k++) {  // join: the main stream continues when the extra lanes are done
-            HIP_OK(hipEventRecord(xl_[k].join, xl_[k].stream));
-            HIP_OK(hipStreamWaitEvent(st, xl_[k].join, 0));
-        }
-        if (if_res && cond_on_)
-            for (int k = 0; k < np; k++) residual_conditioned(ctx[k]);
-        HIP_OK(hipEventRecord(ev_[1], st));
-        fwd_steps_ += (long long)np * (nSteps - 1);
-        HIP_OK(hipStreamSynchronize(st));
-        {
-            float ms = 0.f;
-            HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-            fwd_ms_ += ms;
-        }
-
-        for (int k = 0; k < np; k++) {
-            if (to_store) {
-                store_gather(ctx[k]);
-            } else if (!if_res) {
-                export_gathers(ctx[k]);
-            } else if (ctx[k].scratch) {
-                scratch_dumps(ctx[k]);
-            }
-        }
-        if (withAdj)
-            for (int k = 0; k < np; k++) backward(ctx[k]);
-        is += np;
-    }
-    if (withAdj && grad_stf) {  // rows indexed by local shot position (libCUFD.cu:671-673)
-        h_gstf.resize((size_t)group_size * nSteps);
-        HIP_OK(hipMemcpy(h_gstf.data(), stf_grad_, h_gstf.size() * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(grad_stf, h_gstf.data(), h_gstf.size() * sizeof(float), hipMemcpyDefault));
-    }
-
-    // ---- outputs: written in place when they live on this device, staged otherwise (host memory, another GPU) ----
-    if (withAdj) {
-        const bool devL = ptr_device(grad_Lambda) == gpu_id_, devM = ptr_device(grad_Mu) == gpu_id_, devD = ptr_device(grad_Den) == gpu_id_;
-        float *oL = devL ? grad_Lambda : grad_stage_, *oM = devM ? grad_Mu : grad_stage_ + dense, *oD = devD ? grad_Den : grad_stage_ + 2 * dense;
-        launch_finalize_gradients(st, g, md_, acc_, oL, oM, oD);
-        launches_++;
-        if (!devL) HIP_OK(hipMemcpyAsync(grad_Lambda, oL, dense * sizeof(float), hipMemcpyDefault, st));
-        if (!devM) HIP_OK(hipMemcpyAsync(grad_Mu, oM, dense * sizeof(float), hipMemcpyDefault, st));
-        if (!devD) HIP_OK(hipMemcpyAsync(grad_Den, oD, dense * sizeof(float), hipMemcpyDefault, st));
-    }
-    if (if_res && misfit) {
-        double sumsq = 0.0;
-        HIP_OK(hipMemcpyAsync(&sumsq, scal_, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        const float mf = (float)(0.5 * sumsq);  // libCUFD.cu:776
-        HIP_OK(hipMemcpy(misfit, &mf, sizeof(float), hipMemcpyDefault));
-    }
-    if (!async) {
-        HIP_OK(hipStreamSynchronize(st));
-    } else if (!ext_stream) {  // later work on the default stream sees this call's outputs
-        HIP_OK(hipEventRecord(ev_order_, st));
-        HIP_OK(hipStreamWaitEvent(nullptr, ev_order_, 0));
-    }
-    total_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    last_shots_ = group_size;
-    last_calc_ = calc_id;
 }
 
 // Test hook (sepfwi_debug_field): one wavefield of one forward lane as the last call left it, dense (nzc, nx).
@@ -1100,7 +333,10 @@ void Session::stats(sepfwi_stats *out) const {
     out->fwd_steps = fwd_steps_;
     out->bwd_steps = bwd_steps_;
     out->launches = launches_;
-    out->device_bytes = device_bytes_;
+    out->device_bytes = device_bytes_ + obs_->device_bytes();
+    out->obs_device_bytes = obs_->device_bytes();
+    out->obs_host_bytes = obs_->host_bytes();
+    out->obs_evictions = obs_->evictions();
     out->probe_kernel_us = probe_calls_ ? probe_us_ / (double)probe_calls_ : 0.0;
     out->probe_calls = probe_calls_;
     // one forward pass = N_c*(nSteps-1); fwd+adj = 3x (forward, reconstruction, adjoint)

@@ -12,14 +12,12 @@
 #include "../../include/sepfwi.h"
 #include "conditioning.hpp"
 #include "config.hpp"
+#include "errors.hpp"
 #include "fwi_types.hpp"
 #include "kernels.hpp"
+#include "obs_store.hpp"
 
 namespace sepfwi {
-
-struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
-struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
-struct CourantError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 class Session {
   public:
@@ -44,19 +42,68 @@ class Session {
 
   private:
     template <class T> T *dalloc(size_t n);
-    const float *observed_ett(int shot_id, int nrec, hipStream_t st);
-    long long pack_offset(int shot_id, int nrec);
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void order_after_null_stream(hipStream_t st);
     void condition_gather(hipStream_t st, float *gather_rec_major, int shot_id, int nrec);
 
-    struct ObsEntry {
-        float *d_ett = nullptr;  // [nSteps][nrec]; with data conditioning: the CONDITIONED gather, [nrec][nSteps]
-        size_t bytes = 0;
-        long long size = 0, mtime_ns = 0;
-        bool from_memory = false;  // handed over through sepfwi_set_observed: no file behind it
+    // ---- one cufd call (run): its state and its passes -------------------------------------------------------------------
+    struct Call {  // what every pass of one call shares; ONE snapshot of the kernel options
+        KernelOptions opt;
+        hipStream_t st = nullptr;
+        bool if_res = false, with_adj = false, to_store = false;
+        int group_size = 0;
+        const int *shot_ids = nullptr;
+        std::vector<float> stf_rows;  // tapered source traces of the call's shots (host)
+        float src_scale = 0.0f;
+        int n_probe = 0;              // HIP-event pairs handed out in the running backward pass
     };
+    struct ShotCtx {  // one shot of the call in the lane it runs in
+        int is, id, nrec, comps;
+        const Shot *sh;
+        const int *rec;
+        const float *stf_s, *d_obs;
+        const float *sens;  // directional sensitivities of this shot's channels (device) or null
+        bool scratch;
+        LineRec line;
+        float *state;  // [5 fields | 8 memory variables] of this lane
+        Fields fld;
+        PmlMem mem;
+        float *frame, *syn, *res;
+        hipStream_t st;
+    };
+    struct BwdLane {  // stream + backward-pass memory variables + adjoint fields + imaging accumulators
+        hipStream_t s;
+        PmlMem bm;
+        Fields adj;
+        ImgAcc acc;
+    };
+    void prepare_media(Call &c, const float *Lambda, const float *Mu, const float *Den);
+    void prepare_buffers(Call &c, const float *stf);
+    ShotCtx make_ctx(const Call &c, int is, int lane, hipStream_t lane_st, bool with_obs = true);
+    void use_state(ShotCtx &x, float *state) const;
+    float *syn_of(const ShotCtx &x, int comp) const { return x.syn + (size_t)comp * data_len_; }
+    bool forward_inline(const Call &c, const ShotCtx &x) const { return x.line.n > 0 && !(x.comps & 1) && c.opt.line_fuse != 0; }
+    // forward pass of one shot, stream form (libCUFD.cu:268-332)
+    void forward_init(const ShotCtx &x);
+    void forward_step(const Call &c, const ShotCtx &x, int it, bool inl);
+    void record_column(const ShotCtx &x, int column);
+    void residual(const ShotCtx &x);
+    void residual_conditioned(const Call &c, const ShotCtx &x);
+    // what a forward pass leaves behind, by kind of call
+    void after_forward(Call &c, const ShotCtx &x);
+    void export_gathers(const Call &c, const ShotCtx &x);
+    void scratch_dumps(const Call &c, const ShotCtx &x);
+    // backward pass of one shot, stream form (libCUFD.cu:500-675)
+    void backward_init(const BwdLane &L);
+    void backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it);
+    void backward(Call &c, const ShotCtx &x);
+    hipEvent_t *probe_pair(Call &c, int it);
+    void collect_probes(Call &c);
+    // the two schedules of a call's shots
+    void run_streams(Call &c);
+    void run_batched(Call &c, int Bf, int Bb);
+    void write_outputs(Call &c, float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf);
 
     std::string para_fname_;
     int gpu_id_;
@@ -114,9 +161,7 @@ class Session {
     Media md_{};
     PmlCoef pc_{};
     ImgAcc acc_{};
-    std::map<int, ObsEntry> obs_;
-    std::map<int, std::pair<long long, int>> pack_index_;  // packed observed-data file: shot id -> (byte offset, nrec)
-    long long pack_mtime_ns_ = -1, pack_size_ = -1;
+    std::unique_ptr<ObservedStore> obs_;
 
     double fwd_ms_ = 0, bwd_ms_ = 0, total_ms_ = 0;
     long long fwd_steps_ = 0, bwd_steps_ = 0, launches_ = 0;

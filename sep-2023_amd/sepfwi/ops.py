@@ -117,6 +117,8 @@ class _FwiOps:
         _native.check(rc)
         if calc_id == 1 and gL.device != dev:   # single-process ngpu > 1: every block's results return to the model's device
             gL, gM, gD, misfit = gL.to(dev), gM.to(dev), gD.to(dev), misfit.to(dev)
+        elif calc_id == 0 and misfit.device != dev:   # forward(): the loss follows the model too, whatever gpu_id computed it
+            misfit = misfit.to(dev)
         return misfit, gL, gM, gD, gS
 
     def _device_for(self, t: torch.Tensor, i: int, ngpu: int = 1) -> int:

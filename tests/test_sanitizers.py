@@ -21,3 +21,21 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
         out = subprocess.run([exe, str(seed), "3000"], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_pack_index_and_survey_checks_under_asan_ubsan(tmp_path):
+    """The validation code session.cpp / obs_store.cpp rely on (csrc/host_checks.cpp): index of the packed observed-data file
+    (flipped bytes, truncation, a lying file size) and the survey geometry against the stored grid (receivers and sources on and
+    beyond every edge, coordinate lists shorter than nrec) -- accepted input stays inside the file / grid, everything else throws."""
+    exe = str(tmp_path / "host_checks_sanitize")
+    src = [os.path.join(ROOT, "tests", "native", "host_checks_sanitize.cpp"), os.path.join(ROOT, "sep-2023_amd", "csrc", "host_checks.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-o", exe] + src)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    for seed in (1, 2, 3):
+        out = subprocess.run([exe, str(seed), "1500", str(tmp_path)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.startswith("OK"), out.stdout + out.stderr
+        acc = [int(w) for w in out.stdout.split() if w.isdigit()]
+        assert min(acc) > 0, out.stdout          # every branch (accepted and refused) was exercised
