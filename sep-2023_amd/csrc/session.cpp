@@ -34,23 +34,9 @@ T *Session::dalloc(size_t n) {
     return (T *)p;
 }
 
-Session::Session(const std::string &para_fname, int gpu_id, const std::string &para_text,
-                 const std::string &survey_text, const Params &par, const Survey &survey)
-    : para_fname_(para_fname), gpu_id_(gpu_id), para_text_(para_text), survey_text_(survey_text), par_(par),
-      survey_(survey) {
-    // The data-conditioning keys are dormant in the reference (every call site is commented out, libCUFD.cu:353-457; the one live
-    // line, source_update_adj at :430-433, acts on the pressure residual that is never injected).  Here a key switches its
-    // stage on for the axial-strain gathers (conditioning.hip).  One combination has no defined meaning there either: the
-    // commented lines take the trace norms of the cross-correlation misfit BEFORE the source update and use them after it.
-    if (par.if_src_update && par.if_cross_misfit)
-        throw std::invalid_argument("parameter file: if_src_update together with if_cross_misfit is not supported");
-    cond_on_ = par.if_win || par.has_filter || par.if_cross_misfit || par.if_src_update;
-    HIP_OK(hipSetDevice(gpu_id_));
-    HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
-    for (auto &e : ev_) HIP_OK(hipEventCreate(&e));
-    for (auto &e : probe_ev_) HIP_OK(hipEventCreate(&e));
-
+// grid geometry of the session from the parameter file (Parameter.cpp:41-178, Boundary.cu:17-27)
+void Session::init_grid() {
+    const Params &par = par_;
     Grid &g = g_;
     g.nz = par.nz;
     g.nx = par.nx;
@@ -71,7 +57,13 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     g.nxBnd = par.nx - 2 * par.nPml + 4;
     g.frame_len = 10 * g.nxBnd + 10 * (g.nzBnd - 10);
 
-    // ---- device arrays ----
+}
+
+// [5 fields | 8 C-PML memories | 5 adjoint fields] contiguous (one memset clears a group; the fused kernels take them as bundles),
+// media, accumulators, staging for foreign-memory inputs / outputs (libCUFD.cu:127-146)
+void Session::alloc_arrays() {
+    const Params &par = par_;
+    const Grid &g = g_;
     const size_t n = (size_t)(g.nzc + 4) * (size_t)g.pitch;  // 4 spare rows
     cells_ = n;
     // [5 fields | 8 pml memories | 5 adjoint fields] contiguous so one memset clears a group
@@ -92,7 +84,12 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
     scal_ = dalloc<double>(4);
     cp2_bits_ = dalloc<unsigned int>(4);
 
-    // ---- C-PML profiles (host) -> device, with 1/K precomputed ----
+}
+
+// C-PML profiles (host) -> device, with 1/K precomputed (Cpml.cu:7-117, utilities.cu:243-359)
+void Session::upload_profiles() {
+    const Params &par = par_;
+    const Grid &g = g_;
     {
         const int nzc = g.nzc, nx = g.nx;
         std::vector<float> K(std::max(nzc, nx)), a(K.size()), b(K.size()), Kh(K.size()), ah(K.size()), bh(K.size());
@@ -114,7 +111,11 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
                       dx_, dx_ + nx,  dx_ + 2 * nx,  dx_ + 3 * nx,  dx_ + 4 * nx,  dx_ + 5 * nx};
     }
 
-    // ---- receivers: flat cell index per shot (validated against the grid: host_checks.cpp) ----
+}
+
+// receivers: flat cell index per shot (validated against the grid: host_checks.cpp), directional sensitivities, per-channel windows
+void Session::upload_survey() {
+    const Grid &g = g_;
     {
         const int ns = (int)survey_.shots.size();
         std::vector<int> idx;
@@ -150,6 +151,29 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
         win_ = dalloc<float>(w.size());
         HIP_OK(hipMemcpy(win_, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+}
+
+Session::Session(const std::string &para_fname, int gpu_id, const std::string &para_text,
+                 const std::string &survey_text, const Params &par, const Survey &survey)
+    : para_fname_(para_fname), gpu_id_(gpu_id), para_text_(para_text), survey_text_(survey_text), par_(par),
+      survey_(survey) {
+    // The data-conditioning keys are dormant in the reference (every call site is commented out, libCUFD.cu:353-457; the one live
+    // line, source_update_adj at :430-433, acts on the pressure residual that is never injected).  Here a key switches its
+    // stage on for the axial-strain gathers (conditioning.hip).  One combination has no defined meaning there either: the
+    // commented lines take the trace norms of the cross-correlation misfit BEFORE the source update and use them after it.
+    if (par.if_src_update && par.if_cross_misfit)
+        throw std::invalid_argument("parameter file: if_src_update together with if_cross_misfit is not supported");
+    cond_on_ = par.if_win || par.has_filter || par.if_cross_misfit || par.if_src_update;
+    HIP_OK(hipSetDevice(gpu_id_));
+    HIP_OK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_order_, hipEventDisableTiming));
+    for (auto &e : ev_) HIP_OK(hipEventCreate(&e));
+    for (auto &e : probe_ev_) HIP_OK(hipEventCreate(&e));
+
+    init_grid();
+    alloc_arrays();
+    upload_profiles();
+    upload_survey();
     const size_t dlen = (size_t)std::max(1, survey_.max_nrec) * (size_t)par.nSteps;
     data_len_ = dlen;
     syn_ = dalloc<float>(4 * dlen);  // time-major pr, vx, vz, ett

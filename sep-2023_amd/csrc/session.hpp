@@ -42,6 +42,10 @@ class Session {
 
   private:
     template <class T> T *dalloc(size_t n);
+    void init_grid();        // constructor steps
+    void alloc_arrays();
+    void upload_profiles();
+    void upload_survey();
     void ensure_lanes(int n_lanes, bool with_frames);
     void ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots);
     void order_after_null_stream(hipStream_t st);

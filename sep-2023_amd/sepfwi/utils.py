@@ -35,7 +35,7 @@ def padding(cp, cs, den, nz_orig, nx_orig, nz, nx, nPml, nPad):
 
 def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, data_dir_name,
             if_win=False, filter_para=None, if_src_update=False, scratch_dir_name="", if_cross_misfit=False,
-            das_fiber="horizontal", obs_pack_fname=None, conditioning=None):
+            das_fiber="horizontal", obs_pack_fname=None, conditioning=None, obs_cache_mb=None):
     """Write the one-line parameter JSON (schema of fwi_utils.py:46-83; nz, nx are the PADDED sizes).
     das_fiber (extension): "horizontal" = axial strain exx = vx(x) - vx(x-1), the reference's live
     choice; "vertical" = ezz = vz(z) - vz(z-1) (recording_ezz / res_injection_ezz, Src/utilities.cu:620-641, which the
@@ -65,6 +65,8 @@ def paraGen(nz, nx, dz, dx, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname
         if conditioning not in ("live", "reference"):   # are parsed and ignored, as the reference's driver does (libCUFD.cu:353-457)
             raise ValueError("conditioning must be 'live' or 'reference'")
         para["conditioning"] = conditioning
+    if obs_cache_mb:        # extension: HBM budget [MB] of the session's observed-data store (beyond it: pinned host memory)
+        para["obs_cache_mb"] = int(obs_cache_mb)
     if obs_pack_fname:      # extension: one packed file of axial-strain gathers instead of four files per shot
         para["obs_pack_fname"] = obs_pack_fname
     with open(para_fname, "w") as fp:

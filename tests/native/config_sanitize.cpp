@@ -16,7 +16,7 @@ using namespace sepfwi;
 static const char *PARA =
     "{\"nz\": 96, \"nx\": 80, \"dz\": 10.0, \"dx\": 10.0, \"nSteps\": 100, \"dt\": 0.001, \"f0\": 10.0, \"nPoints_pml\": 10, "
     "\"nPad\": 12, \"survey_fname\": \"s.json\", \"data_dir_name\": \"D\", \"das_fiber\": \"vertical\", \"if_win\": true, "
-    "\"filter\": [0.0, 0.0, 2.0, 2.5], \"scratch_dir_name\": \"S\", \"if_src_update\": true, \"obs_pack_fname\": \"D/pack.bin\", "
+    "\"filter\": [0.0, 0.0, 2.0, 2.5], \"scratch_dir_name\": \"S\", \"if_src_update\": true, \"obs_pack_fname\": \"D/pack.bin\", \"obs_cache_mb\": 64, "
     "\"if_cross_misfit\": false}";
 static const char *SURVEY =
     "{\"nShots\": 2, \"shot0\": {\"z_src\": 2, \"x_src\": 5, \"nrec\": 3, \"z_rec\": [4, 4, 4], \"x_rec\": [1, 2, 3], \"src_rxz\": 1.0, "
@@ -31,7 +31,7 @@ int main(int argc, char **argv) {
     // 1. the well-formed documents parse to the expected values
     Params p = parse_params(PARA);
     Survey s = parse_survey(SURVEY, p.nPml, p.if_win);
-    if (!p.if_src_update || p.obs_pack_fname != "D/pack.bin" || p.if_cross_misfit || p.nz != 96 || p.nx != 80 || p.fiber != 1 || !p.if_win || !p.has_filter || s.nShots != 2 || s.shots[1].nrec != 2 ||
+    if (!p.if_src_update || p.obs_pack_fname != "D/pack.bin" || p.obs_cache_mb != 64 || p.if_cross_misfit || p.nz != 96 || p.nx != 80 || p.fiber != 1 || !p.if_win || !p.has_filter || s.nShots != 2 || s.shots[1].nrec != 2 ||
         s.shots[0].x_rec[2] != 3 + p.nPml || p.filter[3] != 2.5f || s.shots[0].win_end[2] != 0.07f || s.shots[0].weights[1] != 0.5f ||
         s.shots[0].src_weight != 1.5f || s.shots[0].sens[3 * 1 + 1] != 0.5f || s.shots[0].sens[3 * 1 + 2] != 0.1f || !s.shots[1].weights.empty()) {
         printf("FAIL: reference documents mis-parsed\n");
