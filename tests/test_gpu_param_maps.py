@@ -60,7 +60,7 @@ def test_fused_rock_physics_maps_equal_torch_expressions(tmp_path, hip_ops, cls_
     reference's arrangement).  VRH forward: bit for bit (same float32 operations in the same order).  Gassmann forward: to two
     units in the last place of the velocities -- it takes two square roots, and torch's vectorised CPU sqrt is itself not
     correctly rounded (0.7 % of its results differ from IEEE sqrt by one ulp), so there is no bit pattern to match.  Chain rule:
-    reverse-mode over the same operation list as autograd, <= 1e-6 (VRH) / 1e-5 (Gassmann: the roots again) of the largest entry."""
+    reverse-mode over the same operation list as autograd, <= 1e-6 of the largest entry (measured 1.5e-7 / 4.2e-7)."""
     from sepfwi import modules as M
     pb = P.make_problem(str(tmp_path), nz=37, nx=70, nPml=9, nSteps=10, nshots=1, nPad=5)
     rng = np.random.default_rng(11)
@@ -90,7 +90,10 @@ def test_fused_rock_physics_maps_equal_torch_expressions(tmp_path, hip_ops, cls_
         # Lambda = rho (vp^2 - 2 vs^2) / 1e6: two ulp of each velocity, measured against the minuend
         m_c = den_c.astype(np.float64) * (lam_c.astype(np.float64) / den_c + 2 * mu_c.astype(np.float64) / den_c)
         assert np.abs(outs["cuda"][0] - lam_c).max() <= 1e-6 * np.abs(m_c).max()
-    tol = 1e-6 if cls_name.endswith("VRH") else 1e-5
+    tol = 1e-6      # measured: 1.5e-7 (VRH), 4.2e-7 (Gassmann)
+    print("%s: fused vs torch-on-CPU, forward max rel. deviation (Lambda, Mu, Den) %s; chain rule max deviation / max entry %s" % (
+        cls_name, ["%.1e" % (np.abs(outs["cuda"][k] - outs["cpu"][k]).max() / np.abs(outs["cpu"][k]).max()) for k in range(3)],
+        ["%.1e" % (np.abs(outs["cuda"][k] - outs["cpu"][k]).max() / np.abs(outs["cpu"][k]).max()) for k in range(3, 6)]))
     for k in range(3, 6):
         scale = np.abs(outs["cpu"][k]).max()
         assert scale > 0 and np.abs(outs["cuda"][k] - outs["cpu"][k]).max() <= tol * scale, (cls_name, "backward", k, np.abs(outs["cuda"][k] - outs["cpu"][k]).max() / scale)
