@@ -266,6 +266,7 @@ def main():
                     help="shots each GPU processes per step (3: the forward passes of the three overlap on three streams)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-call32", action="store_true", help="skip the one 32-shot call of configs[2] reported as `call32` at N = 1")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="library option for this run (sepfwi_set_option), e.g. bwd_fuse=2")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box; use with --backend gloo)")
     args = ap.parse_args()
 
@@ -329,6 +330,9 @@ def main():
 
         from sepfwi import _native
         _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_b launch
+        for kv in args.option:
+            k_, v_ = kv.split("=")
+            _native.check(_native.lib().sepfwi_set_option(k_.encode(), int(v_)))
         for w in range(W):
             step(w % per_rank_steps)
         torch.cuda.synchronize()
@@ -340,6 +344,7 @@ def main():
         t0 = time.perf_counter()
         fwd_ms = bwd_ms = call_ms = 0.0
         probe_us, probe_n = 0.0, 0
+        persist_steps = 0
         for s in range(K):
             step(s)
             st = fwi_ops.stats(pb["para_fname"], local)
@@ -349,6 +354,7 @@ def main():
             n_launch = st["launches"]       # kernel launches of the last call (every shot, both time loops, set-up and finalisation)
             probe_us += st["probe_kernel_us"] * st["probe_calls"]
             probe_n += st["probe_calls"]
+            persist_steps += st.get("persist_steps", 0)
         torch.cuda.synchronize()
         if world > 1:
             td.barrier()
@@ -376,17 +382,19 @@ def main():
             # roofline of the dominant kernel group, measured live with HIP events on the session stream
             # (sepfwi_stats.fwd_ms / bwd_ms): algorithmic bytes per time step / measured time per time step.
             nst = K * spr * (args.nsteps - 1)
-            traffic = traffic_ratio = None
+            traffic = traffic_ratio = traffic_p = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
             if os.path.exists(tf) and args.nz == 1000 and args.nx == 2000:
                 tj = json.load(open(tf))
                 # the counters were collected on ONE version of the kernels: a changed kernel file makes them stale -> null
                 if tj.get("kernel_source_sha256") == kernel_source_digest():
                     traffic = tj.get("k_bwd_b_bytes_per_launch")
+                    traffic_p = tj.get("k_bwd_persist_bytes_per_time_step")     # persistent loop: PMC bytes of a launch / its time steps
                     # PMC bytes / algorithmic bytes, per kernel and per time step (1.0 = every array touched exactly once)
-                    pmc = {k: tj[k + "_bytes_per_launch"] for k in ALGO_BYTES_PER_CELL}
+                    pmc = {k: tj[k + "_bytes_per_launch"] for k in ALGO_BYTES_PER_CELL if k + "_bytes_per_launch" in tj}
                     traffic_ratio = {k: round(pmc[k] / (ALGO_BYTES_PER_CELL[k] * pb["n_c"]), 3) for k in pmc}
-                    traffic_ratio["bwd_step"] = round((pmc["k_bwd_a"] + pmc["k_bwd_b"]) / (124.0 * pb["n_c"]), 3)
+                    if "k_bwd_a" in pmc and "k_bwd_b" in pmc:
+                        traffic_ratio["bwd_step"] = round((pmc["k_bwd_a"] + pmc["k_bwd_b"]) / (124.0 * pb["n_c"]), 3)
                     traffic_ratio["fwd_step"] = round((pmc["k_stress_fwd_save"] + pmc["k_velocity_fwd"]) / (BYTES_FWD * pb["n_c"]), 3)
             if args.mode == "fwdadj" and probe_n > 0:
                 per_step_us = probe_us / probe_n
@@ -396,6 +404,11 @@ def main():
                 per_step_us = bwd_ms * 1e3 / nst
                 ach = pb["n_c"] * 124.0 / (per_step_us * 1e-6) / 1e9
                 kern = "whole backward time step"
+                if persist_steps > 0:      # the backward pass ran as ONE persistent launch per shot: that kernel IS the backward step (124 B per cell)
+                    kern = "k_bwd_persist (one launch per shot and backward pass; %d time steps by HIP events around the passes)" % persist_steps
+                    traffic = traffic_p
+                    if traffic_ratio is not None and traffic_p is not None:
+                        traffic_ratio["bwd_step"] = round(traffic_p / (124.0 * pb["n_c"]), 3)
             else:
                 per_step_us = fwd_ms * 1e3 / nst
                 ach = pb["n_c"] * BYTES_FWD / (per_step_us * 1e-6) / 1e9

@@ -136,6 +136,7 @@ typedef struct sepfwi_stats {
     long long obs_device_bytes; /* observed-data store: gathers resident in HBM (part of device_bytes)            */
     long long obs_host_bytes;   /* ... and in the pinned host tier (only with a budget, key / option "obs_cache_mb") */
     long long obs_evictions;    /* gathers moved HBM -> host tier since the store was created                       */
+    long long persist_steps;    /* backward time steps of the call that ran inside the persistent loop (option bwd_fuse = 4) */
 } sepfwi_stats;
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 

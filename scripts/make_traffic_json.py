@@ -38,9 +38,19 @@ for pat, key in keys.items():
     f = [v for k, v in fetch.items() if pat in k]
     w = [v for k, v in write.items() if pat in k]
     if not f or not w:
+        if pat.startswith("k_bwd_"):      # the two-launch step does not run where the persistent loop does
+            continue
         sys.exit("missing %s" % pat)
     res[key + "_fetch_kib"] = f[0]
     res[key + "_write_kib"] = w[0]
     res[key + "_bytes_per_launch"] = int(round((2.0 * f[0] + w[0]) * 1024))
+# the persistent backward loop: one launch per shot = (nsteps - 1) time steps of the PMC command (bench.py --nsteps 400)
+fp_ = [v for k, v in fetch.items() if "k_bwd_persist" in k]
+wp_ = [v for k, v in write.items() if "k_bwd_persist" in k]
+if fp_ and wp_:
+    steps = int(sys.argv[2]) - 1 if len(sys.argv) > 2 else 399
+    res["k_bwd_persist_fetch_kib_per_launch"] = fp_[0]
+    res["k_bwd_persist_write_kib_per_launch"] = wp_[0]
+    res["k_bwd_persist_bytes_per_time_step"] = int(round((2.0 * fp_[0] + wp_[0]) * 1024 / steps))
 json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k.endswith("per_launch")}, indent=1))

@@ -33,6 +33,7 @@
 
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -103,16 +104,59 @@ __device__ __forceinline__ float ave_mu_at(const Grid &g, const Media &md, size_
     return md.ave_mu[i];
 }
 
+
+// Imaging accumulators behind an accessor, so that the same bodies serve the per-step launches (accumulators in HBM, AccG)
+// and the persistent time loop (accumulators of the workgroup's own tile in LDS, AccT below).
+enum { ACC_LAM = 0, ACC_MU = 1, ACC_XZ = 2, ACC_A = 3, ACC_B = 4 };
+template <int K>
+__device__ __forceinline__ float *acc_array(const ImgAcc &a) {
+    return K == ACC_LAM ? a.lam : K == ACC_MU ? a.mu : K == ACC_XZ ? a.xz : K == ACC_A ? a.a : a.b;
+}
+struct AccG {
+    ImgAcc p;
+    template <int K> __device__ __forceinline__ float ld(size_t i) const { return acc_array<K>(p)[i]; }
+    template <int K> __device__ __forceinline__ void st(size_t i, float v) const { acc_array<K>(p)[i] = v; }
+};
+typedef __attribute__((address_space(3))) float lds_float;
+// MASK bit K set: accumulator K of this lane's cell lives in LDS at cell[rank of K among the set bits * stride]
+template <int MASK>
+struct AccT {
+    ImgAcc p;
+    lds_float *cell;  // this lane's slot of the current row segment
+    int stride;       // floats between two LDS-resident accumulator arrays of the tile
+    template <int K> __device__ __forceinline__ float ld(size_t i) const {
+        if constexpr ((MASK >> K) & 1) return cell[__builtin_popcount(MASK & ((1 << K) - 1)) * stride];
+        else return acc_array<K>(p)[i];
+    }
+    template <int K> __device__ __forceinline__ void st(size_t i, float v) const {
+        if constexpr ((MASK >> K) & 1) cell[__builtin_popcount(MASK & ((1 << K) - 1)) * stride] = v;
+        else acc_array<K>(p)[i] = v;
+    }
+};
+
+// How the backward bodies touch the wavefields, the adjoint fields and the C-PML memories.  MemPlain: ordinary loads / stores
+// (every per-step launch; inside the persistent loop every row segment whose stencils stay within one XCD's band of rows).
+// MemAgent: agent-scope accesses (`sc1`: loads bypass the vector L1 and are served coherently, stores are written through) for
+// the persistent loop's segments next to another XCD's band -- the L2s of different XCDs are not coherent with each other.
+struct MemPlain {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+struct MemAgent {
+    static __device__ __forceinline__ float ld(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void st(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // stress update
 // ---------------------------------------------------------------------------------------------
-template <bool FWD, bool SAVE>
+template <bool FWD, bool SAVE, class ACC, class MEM = MemPlain>
 __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
-                                            const Fields &adj, const ImgAcc &acc, const LineRec &lr) {
+                                            const Fields &adj, const ACC &acc, const LineRec &lr) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -185,23 +229,23 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
         if (!interior && s < 0) return;
         float szz = 0.f, sxx = 0.f, sxz = 0.f;
         if (interior) {
-            szz = f.szz[i];
-            sxx = f.sxx[i];
-            sxz = f.sxz[i];
+            szz = MEM::ld(&f.szz[i]);
+            sxx = MEM::ld(&f.sxx[i]);
+            sxz = MEM::ld(&f.sxz[i]);
             if (z == z_src && x == x_src) {  // add_source(isFor=false) comes first (libCUFD.cu:566-569)
                 szz -= src_amp;
                 sxx -= src_amp;
             }
-            const float dvz_dz = dminus(f.vz[i - 2 * P], f.vz[i - P], f.vz[i], f.vz[i + P], g.rdz);
-            const float dvx_dx = dminus(f.vx[i - 2], f.vx[i - 1], f.vx[i], f.vx[i + 1], g.rdx);
-            const float dvx_dz = dplus(f.vx[i - P], f.vx[i], f.vx[i + P], f.vx[i + 2 * P], g.rdz);
-            const float dvz_dx = dplus(f.vz[i - 1], f.vz[i], f.vz[i + 1], f.vz[i + 2], g.rdx);
+            const float dvz_dz = dminus(MEM::ld(&f.vz[i - 2 * P]), MEM::ld(&f.vz[i - P]), MEM::ld(&f.vz[i]), MEM::ld(&f.vz[i + P]), g.rdz);
+            const float dvx_dx = dminus(MEM::ld(&f.vx[i - 2]), MEM::ld(&f.vx[i - 1]), MEM::ld(&f.vx[i]), MEM::ld(&f.vx[i + 1]), g.rdx);
+            const float dvx_dz = dplus(MEM::ld(&f.vx[i - P]), MEM::ld(&f.vx[i]), MEM::ld(&f.vx[i + P]), MEM::ld(&f.vx[i + 2 * P]), g.rdz);
+            const float dvz_dx = dplus(MEM::ld(&f.vz[i - 1]), MEM::ld(&f.vz[i]), MEM::ld(&f.vz[i + 1]), MEM::ld(&f.vz[i + 2]), g.rdx);
             const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
             const bool img = g.dt_img != 0.0f;  // launch-uniform: option img_every images every k-th step only
             float za = 0.f, xa = 0.f, sa = 0.f, g_lam = 0.f, g_mu = 0.f, g_xz = 0.f;
             if (img) {
-                za = adj.szz[i]; xa = adj.sxx[i]; sa = adj.sxz[i];
-                g_lam = acc.lam[i]; g_mu = acc.mu[i]; g_xz = acc.xz[i];
+                za = MEM::ld(&adj.szz[i]); xa = MEM::ld(&adj.sxx[i]); sa = MEM::ld(&adj.sxz[i]);
+                g_lam = acc.template ld<ACC_LAM>(i); g_mu = acc.template ld<ACC_MU>(i); g_xz = acc.template ld<ACC_XZ>(i);
             }
             const float l2m = lam + 2.0f * mu;
             szz -= (l2m * dvz_dz + lam * dvx_dx) * g.dt;
@@ -209,9 +253,9 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             sxz -= amu * (dvx_dz + dvz_dx) * g.dt;
             if (img) {
                 // imaging condition, el_stress.cu:108-115 (constant factors deferred to finalize)
-                acc.lam[i] = g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img;
-                acc.mu[i] = g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img;
-                acc.xz[i] = g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img;
+                acc.template st<ACC_LAM>(i, g_lam + -(za + xa) * (dvz_dz + dvx_dx) * g.dt_img);
+                acc.template st<ACC_MU>(i, g_mu + -2.0f * (za * dvz_dz + xa * dvx_dx) * g.dt_img);
+                acc.template st<ACC_XZ>(i, g_xz + -sa * (dvx_dz + dvz_dx) * g.dt_img);
             }
         }
         if (s >= 0) {  // to_bnd(szz, sxz, sxx) overrides the frame (libCUFD.cu:582)
@@ -220,9 +264,9 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             sxz = frame_t[L + s];
             sxx = frame_t[2 * L + s];
         }
-        f.szz[i] = szz;
-        f.sxx[i] = sxx;
-        f.sxz[i] = sxz;
+        MEM::st(&f.szz[i], szz);
+        MEM::st(&f.sxx[i], sxx);
+        MEM::st(&f.sxz[i], sxz);
     }
 }
 
@@ -245,11 +289,11 @@ __device__ __forceinline__ void buoyancies(const Grid &g, const Media &md, size_
     }
 }
 
-template <bool FWD>
+template <bool FWD, class ACC, class MEM = MemPlain>
 __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
                                               float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
-                                              const ImgAcc &acc) {
+                                              const ACC &acc) {
     const int z = c.z, x = c.x, P = g.pitch;
     if (z >= g.nzc || x >= g.nx) return;
     const size_t i = c.i;
@@ -283,29 +327,29 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
         f.vx[i] = vx0 + (dsxz_dz + dsxx_dx) * bb * g.dt;
     } else {
         // source_grad uses the adjoint stresses as they stand at the start of the step (libCUFD.cu:547)
-        if (z == z_src && x == x_src) *stf_grad_it = -(adj.szz[i] + src_rxz * adj.sxx[i]) * g.dt;
+        if (z == z_src && x == x_src) *stf_grad_it = -(MEM::ld(&adj.szz[i]) + src_rxz * MEM::ld(&adj.sxx[i])) * g.dt;
         const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
         const int s = frame_slot(g, z, x);
         if (!interior && s < 0) return;
         float vz = 0.f, vx = 0.f;
         if (interior) {
-            const float dszz_dz = dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
-            const float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
-            const float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
-            const float dsxx_dx = dplus(f.sxx[i - 1], f.sxx[i], f.sxx[i + 1], f.sxx[i + 2], g.rdx);
+            const float dszz_dz = dplus(MEM::ld(&f.szz[i - P]), MEM::ld(&f.szz[i]), MEM::ld(&f.szz[i + P]), MEM::ld(&f.szz[i + 2 * P]), g.rdz);
+            const float dsxz_dx = dminus(MEM::ld(&f.sxz[i - 2]), MEM::ld(&f.sxz[i - 1]), MEM::ld(&f.sxz[i]), MEM::ld(&f.sxz[i + 1]), g.rdx);
+            const float dsxz_dz = dminus(MEM::ld(&f.sxz[i - 2 * P]), MEM::ld(&f.sxz[i - P]), MEM::ld(&f.sxz[i]), MEM::ld(&f.sxz[i + P]), g.rdz);
+            const float dsxx_dx = dplus(MEM::ld(&f.sxx[i - 1]), MEM::ld(&f.sxx[i]), MEM::ld(&f.sxx[i + 1]), MEM::ld(&f.sxx[i + 2]), g.rdx);
             const bool img = g.dt_img != 0.0f;  // launch-uniform
             float g_a = 0.f, g_b = 0.f, avz = 0.f, avx = 0.f;
             if (img) {
-                g_a = acc.a[i]; g_b = acc.b[i]; avz = adj.vz[i]; avx = adj.vx[i];
+                g_a = acc.template ld<ACC_A>(i); g_b = acc.template ld<ACC_B>(i); avz = MEM::ld(&adj.vz[i]); avx = MEM::ld(&adj.vx[i]);
             }
             float ba, bb;
             buoyancies(g, md, i, ba, bb);
-            vz = f.vz[i] - (dszz_dz + dsxz_dx) * ba * g.dt;
-            vx = f.vx[i] - (dsxz_dz + dsxx_dx) * bb * g.dt;
+            vz = MEM::ld(&f.vz[i]) - (dszz_dz + dsxz_dx) * ba * g.dt;
+            vx = MEM::ld(&f.vx[i]) - (dsxz_dz + dsxx_dx) * bb * g.dt;
             if (img) {
                 // density imaging, el_velocity.cu:101-104 (the -byc^2/2 factor is applied in finalize)
-                acc.a[i] = g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img;
-                acc.b[i] = g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img;
+                acc.template st<ACC_A>(i, g_a + -avz * (dszz_dz + dsxz_dx) * g.dt_img);
+                acc.template st<ACC_B>(i, g_b + -avx * (dsxz_dz + dsxx_dx) * g.dt_img);
             }
         }
         if (s >= 0) {  // to_bnd(vz, vx) (libCUFD.cu:563)
@@ -313,8 +357,8 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             vz = frame_t[3 * L + s];
             vx = frame_t[4 * L + s];
         }
-        f.vz[i] = vz;
-        f.vx[i] = vx;
+        MEM::st(&f.vz[i], vz);
+        MEM::st(&f.vx[i], vx);
     }
 }
 
@@ -349,6 +393,7 @@ struct VelAdjIn {
     float sxz_zm2, sxz_zm1, sxz_0, sxz_zp1, sxz_xm2, sxz_xm1, sxz_xp1;
     float vx, vz, lam, mu, amu, rKx, rKxh, rKz, rKzh;
 };
+template <class MEM = MemPlain>
 __device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell &c, const Fields &f, const Media &md,
                                                       const PmlCoef &pc) {
     VelAdjIn q;
@@ -356,17 +401,18 @@ __device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell 
     q.on = !(z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3);
     if (!q.on) return q;
     const size_t i = c.i;
-    q.szz_xm1 = f.szz[i - 1]; q.szz_0 = f.szz[i]; q.szz_xp1 = f.szz[i + 1]; q.szz_xp2 = f.szz[i + 2];
-    q.szz_zm1 = f.szz[i - P]; q.szz_zp1 = f.szz[i + P]; q.szz_zp2 = f.szz[i + 2 * P];
-    q.sxx_xm1 = f.sxx[i - 1]; q.sxx_0 = f.sxx[i]; q.sxx_xp1 = f.sxx[i + 1]; q.sxx_xp2 = f.sxx[i + 2];
-    q.sxx_zm1 = f.sxx[i - P]; q.sxx_zp1 = f.sxx[i + P]; q.sxx_zp2 = f.sxx[i + 2 * P];
-    q.sxz_zm2 = f.sxz[i - 2 * P]; q.sxz_zm1 = f.sxz[i - P]; q.sxz_0 = f.sxz[i]; q.sxz_zp1 = f.sxz[i + P];
-    q.sxz_xm2 = f.sxz[i - 2]; q.sxz_xm1 = f.sxz[i - 1]; q.sxz_xp1 = f.sxz[i + 1];
-    q.vx = f.vx[i]; q.vz = f.vz[i];
+    q.szz_xm1 = MEM::ld(&f.szz[i - 1]); q.szz_0 = MEM::ld(&f.szz[i]); q.szz_xp1 = MEM::ld(&f.szz[i + 1]); q.szz_xp2 = MEM::ld(&f.szz[i + 2]);
+    q.szz_zm1 = MEM::ld(&f.szz[i - P]); q.szz_zp1 = MEM::ld(&f.szz[i + P]); q.szz_zp2 = MEM::ld(&f.szz[i + 2 * P]);
+    q.sxx_xm1 = MEM::ld(&f.sxx[i - 1]); q.sxx_0 = MEM::ld(&f.sxx[i]); q.sxx_xp1 = MEM::ld(&f.sxx[i + 1]); q.sxx_xp2 = MEM::ld(&f.sxx[i + 2]);
+    q.sxx_zm1 = MEM::ld(&f.sxx[i - P]); q.sxx_zp1 = MEM::ld(&f.sxx[i + P]); q.sxx_zp2 = MEM::ld(&f.sxx[i + 2 * P]);
+    q.sxz_zm2 = MEM::ld(&f.sxz[i - 2 * P]); q.sxz_zm1 = MEM::ld(&f.sxz[i - P]); q.sxz_0 = MEM::ld(&f.sxz[i]); q.sxz_zp1 = MEM::ld(&f.sxz[i + P]);
+    q.sxz_xm2 = MEM::ld(&f.sxz[i - 2]); q.sxz_xm1 = MEM::ld(&f.sxz[i - 1]); q.sxz_xp1 = MEM::ld(&f.sxz[i + 1]);
+    q.vx = MEM::ld(&f.vx[i]); q.vz = MEM::ld(&f.vz[i]);
     q.lam = md.lam[i]; q.mu = md.mu[i]; q.amu = ave_mu_at(g, md, i, q.mu);
     load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
+template <class MEM = MemPlain>
 __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
                                                    const PmlMem &m, const Media &md, const PmlCoef &pc, const LineRec &lr) {
     if (!q.on) return;
@@ -388,12 +434,12 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
     const float dsxz_dx = -dminus(q.sxz_xm2, q.sxz_xm1, q.sxz_0, q.sxz_xp1, g.rdx);
     float upz = l2m * dszz_dz * q.rKz * g.dt + lam * dsxx_dz * q.rKz * g.dt + amu * q.rKxh * dsxz_dx * g.dt;
     if (px) {
-        upd += pc.a_x[x] * -dplus(m.dvx_dx[i - 1], m.dvx_dx[i], m.dvx_dx[i + 1], m.dvx_dx[i + 2], g.rdx);
-        upz += pc.a_xh[x] * -dminus(m.dvz_dx[i - 2], m.dvz_dx[i - 1], m.dvz_dx[i], m.dvz_dx[i + 1], g.rdx);
+        upd += pc.a_x[x] * -dplus(MEM::ld(&m.dvx_dx[i - 1]), MEM::ld(&m.dvx_dx[i]), MEM::ld(&m.dvx_dx[i + 1]), MEM::ld(&m.dvx_dx[i + 2]), g.rdx);
+        upz += pc.a_xh[x] * -dminus(MEM::ld(&m.dvz_dx[i - 2]), MEM::ld(&m.dvz_dx[i - 1]), MEM::ld(&m.dvz_dx[i]), MEM::ld(&m.dvz_dx[i + 1]), g.rdx);
     }
     if (pz) {
-        upd += pc.a_zh[z] * -dminus(m.dvx_dz[i - 2 * P], m.dvx_dz[i - P], m.dvx_dz[i], m.dvx_dz[i + P], g.rdz);
-        upz += pc.a_z[z] * -dplus(m.dvz_dz[i - P], m.dvz_dz[i], m.dvz_dz[i + P], m.dvz_dz[i + 2 * P], g.rdz);
+        upd += pc.a_zh[z] * -dminus(MEM::ld(&m.dvx_dz[i - 2 * P]), MEM::ld(&m.dvx_dz[i - P]), MEM::ld(&m.dvx_dz[i]), MEM::ld(&m.dvx_dz[i + P]), g.rdz);
+        upz += pc.a_z[z] * -dplus(MEM::ld(&m.dvz_dz[i - P]), MEM::ld(&m.dvz_dz[i]), MEM::ld(&m.dvz_dz[i + P]), MEM::ld(&m.dvz_dz[i + 2 * P]), g.rdz);
     }
     const float vx = q.vx + upd;
     const float vz = q.vz + upz;
@@ -406,25 +452,26 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
             if (r >= 0 && r < lr.n) vs += lr.res[r];
             if (r + 1 >= 0 && r + 1 < lr.n) vs -= lr.res[r + 1];
         }
-        f.vx[i] = vs;
+        MEM::st(&f.vx[i], vs);
     }
-    f.vz[i] = vz;
+    MEM::st(&f.vz[i], vz);
     if (px || pz) {  // the buoyancies are only needed inside the layers: keep their loads out of the interior
         const float bb = md.byc_b[i], ba = md.byc_a[i];
         if (px) {
-            m.dsxx_dx[i] = pc.b_xh[x] * m.dsxx_dx[i] + bb * vx * g.dt;
-            m.dsxz_dx[i] = pc.b_x[x] * m.dsxz_dx[i] + ba * vz * g.dt;
+            MEM::st(&m.dsxx_dx[i], pc.b_xh[x] * MEM::ld(&m.dsxx_dx[i]) + bb * vx * g.dt);
+            MEM::st(&m.dsxz_dx[i], pc.b_x[x] * MEM::ld(&m.dsxz_dx[i]) + ba * vz * g.dt);
         }
         if (pz) {
-            m.dsxz_dz[i] = pc.b_z[z] * m.dsxz_dz[i] + bb * vx * g.dt;
-            m.dszz_dz[i] = pc.b_zh[z] * m.dszz_dz[i] + ba * vz * g.dt;
+            MEM::st(&m.dsxz_dz[i], pc.b_z[z] * MEM::ld(&m.dsxz_dz[i]) + bb * vx * g.dt);
+            MEM::st(&m.dszz_dz[i], pc.b_zh[z] * MEM::ld(&m.dszz_dz[i]) + ba * vz * g.dt);
         }
     }
 }
+template <class MEM = MemPlain>
 __device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
                                                   const Media &md, const PmlCoef &pc, const LineRec &lr) {
-    const VelAdjIn q = velocity_adj_load(g, c, f, md, pc);
-    velocity_adj_apply(q, g, c, f, m, md, pc, lr);
+    const VelAdjIn q = velocity_adj_load<MEM>(g, c, f, md, pc);
+    velocity_adj_apply<MEM>(q, g, c, f, m, md, pc, lr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,6 +486,7 @@ struct StressAdjIn {
     float vx_zm1, vx_0, vx_zp1, vx_zp2, vx_xm2, vx_xm1, vx_xp1;
     float sxz, sxx, szz, ba, bb, rKx, rKxh, rKz, rKzh;
 };
+template <class MEM = MemPlain>
 __device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell &c, const Fields &f, const Media &md,
                                                        const PmlCoef &pc) {
     StressAdjIn q;
@@ -446,15 +494,16 @@ __device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell
     q.on = !(z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3);
     if (!q.on) return q;
     const size_t i = c.i;
-    q.vz_xm1 = f.vz[i - 1]; q.vz_0 = f.vz[i]; q.vz_xp1 = f.vz[i + 1]; q.vz_xp2 = f.vz[i + 2];
-    q.vz_zm2 = f.vz[i - 2 * P]; q.vz_zm1 = f.vz[i - P]; q.vz_zp1 = f.vz[i + P];
-    q.vx_zm1 = f.vx[i - P]; q.vx_0 = f.vx[i]; q.vx_zp1 = f.vx[i + P]; q.vx_zp2 = f.vx[i + 2 * P];
-    q.vx_xm2 = f.vx[i - 2]; q.vx_xm1 = f.vx[i - 1]; q.vx_xp1 = f.vx[i + 1];
-    q.sxz = f.sxz[i]; q.sxx = f.sxx[i]; q.szz = f.szz[i];
+    q.vz_xm1 = MEM::ld(&f.vz[i - 1]); q.vz_0 = MEM::ld(&f.vz[i]); q.vz_xp1 = MEM::ld(&f.vz[i + 1]); q.vz_xp2 = MEM::ld(&f.vz[i + 2]);
+    q.vz_zm2 = MEM::ld(&f.vz[i - 2 * P]); q.vz_zm1 = MEM::ld(&f.vz[i - P]); q.vz_zp1 = MEM::ld(&f.vz[i + P]);
+    q.vx_zm1 = MEM::ld(&f.vx[i - P]); q.vx_0 = MEM::ld(&f.vx[i]); q.vx_zp1 = MEM::ld(&f.vx[i + P]); q.vx_zp2 = MEM::ld(&f.vx[i + 2 * P]);
+    q.vx_xm2 = MEM::ld(&f.vx[i - 2]); q.vx_xm1 = MEM::ld(&f.vx[i - 1]); q.vx_xp1 = MEM::ld(&f.vx[i + 1]);
+    q.sxz = MEM::ld(&f.sxz[i]); q.sxx = MEM::ld(&f.sxx[i]); q.szz = MEM::ld(&f.szz[i]);
     buoyancies(g, md, i, q.ba, q.bb);
     load_rK(g, pc, z, x, q.rKx, q.rKxh, q.rKz, q.rKzh);
     return q;
 }
+template <class MEM = MemPlain>
 __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
                                                  const PmlMem &m, const Media &md, const PmlCoef &pc) {
     if (!q.on) return;
@@ -476,37 +525,38 @@ __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Gri
     float ux = bb * dvx_dx * q.rKxh * g.dt;
     float uz = ba * dvz_dz * q.rKzh * g.dt;
     if (px) {
-        us += pc.a_x[x] * -dplus(m.dsxz_dx[i - 1], m.dsxz_dx[i], m.dsxz_dx[i + 1], m.dsxz_dx[i + 2], g.rdx);
-        ux += pc.a_xh[x] * -dminus(m.dsxx_dx[i - 2], m.dsxx_dx[i - 1], m.dsxx_dx[i], m.dsxx_dx[i + 1], g.rdx);
+        us += pc.a_x[x] * -dplus(MEM::ld(&m.dsxz_dx[i - 1]), MEM::ld(&m.dsxz_dx[i]), MEM::ld(&m.dsxz_dx[i + 1]), MEM::ld(&m.dsxz_dx[i + 2]), g.rdx);
+        ux += pc.a_xh[x] * -dminus(MEM::ld(&m.dsxx_dx[i - 2]), MEM::ld(&m.dsxx_dx[i - 1]), MEM::ld(&m.dsxx_dx[i]), MEM::ld(&m.dsxx_dx[i + 1]), g.rdx);
     }
     if (pz) {
-        us += pc.a_z[z] * -dplus(m.dsxz_dz[i - P], m.dsxz_dz[i], m.dsxz_dz[i + P], m.dsxz_dz[i + 2 * P], g.rdz);
-        uz += pc.a_zh[z] * -dminus(m.dszz_dz[i - 2 * P], m.dszz_dz[i - P], m.dszz_dz[i], m.dszz_dz[i + P], g.rdz);
+        us += pc.a_z[z] * -dplus(MEM::ld(&m.dsxz_dz[i - P]), MEM::ld(&m.dsxz_dz[i]), MEM::ld(&m.dsxz_dz[i + P]), MEM::ld(&m.dsxz_dz[i + 2 * P]), g.rdz);
+        uz += pc.a_zh[z] * -dminus(MEM::ld(&m.dszz_dz[i - 2 * P]), MEM::ld(&m.dszz_dz[i - P]), MEM::ld(&m.dszz_dz[i]), MEM::ld(&m.dszz_dz[i + P]), g.rdz);
     }
     const float sxz = q.sxz + us;
     const float sxx = q.sxx + ux;
     const float szz = q.szz + uz;
-    f.sxz[i] = sxz;
-    f.sxx[i] = sxx;
-    f.szz[i] = szz;
+    MEM::st(&f.sxz[i], sxz);
+    MEM::st(&f.sxx[i], sxx);
+    MEM::st(&f.szz[i], szz);
     if (wx || wz) {  // lambda, mu, ave_mu only feed the memory variables, which only exist near the layers
         const float amu = md.ave_mu[i];
         const float lam = md.lam[i], mu = md.mu[i];
         const float l2m = lam + 2.0f * mu;
         if (wx) {
-            m.dvz_dx[i] = pc.b_xh[x] * m.dvz_dx[i] + sxz * amu * g.dt;
-            m.dvx_dx[i] = pc.b_x[x] * m.dvx_dx[i] + lam * szz * g.dt + l2m * sxx * g.dt;
+            MEM::st(&m.dvz_dx[i], pc.b_xh[x] * MEM::ld(&m.dvz_dx[i]) + sxz * amu * g.dt);
+            MEM::st(&m.dvx_dx[i], pc.b_x[x] * MEM::ld(&m.dvx_dx[i]) + lam * szz * g.dt + l2m * sxx * g.dt);
         }
         if (wz) {
-            m.dvx_dz[i] = pc.b_zh[z] * m.dvx_dz[i] + sxz * amu * g.dt;
-            m.dvz_dz[i] = pc.b_z[z] * m.dvz_dz[i] + l2m * szz * g.dt + lam * sxx * g.dt;
+            MEM::st(&m.dvx_dz[i], pc.b_zh[z] * MEM::ld(&m.dvx_dz[i]) + sxz * amu * g.dt);
+            MEM::st(&m.dvz_dz[i], pc.b_z[z] * MEM::ld(&m.dvz_dz[i]) + l2m * szz * g.dt + lam * sxx * g.dt);
         }
     }
 }
+template <class MEM = MemPlain>
 __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
                                                 const Media &md, const PmlCoef &pc) {
-    const StressAdjIn q = stress_adj_load(g, c, f, md, pc);
-    stress_adj_apply(q, g, c, f, m, md, pc);
+    const StressAdjIn q = stress_adj_load<MEM>(g, c, f, md, pc);
+    stress_adj_apply<MEM>(q, g, c, f, m, md, pc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,13 +565,13 @@ __device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, co
 template <bool FWD, bool SAVE>
 __global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
                                                  int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc, LineRec lr) {
-    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr);
+    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
 }
 template <bool FWD>
 __global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
                                                    const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
                                                    float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
-    velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
+    velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     velocity_adj_body(g, my_cell(g), f, m, md, pc, LineRec{});
@@ -577,10 +627,10 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
     const Cell c = my_cell(g);
     if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
@@ -600,10 +650,10 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
     if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
     if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, LineRec{});
         velocity_adj_body(g, c, adj, m, md, pc, lr);
     }
 }
@@ -638,7 +688,7 @@ __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev
         lr.d_vz = (s.comps & 4) ? s.syn + 2 * data_len + c0 : nullptr;
         lr.d_ett = (s.comps & 8) ? s.syn + 3 * data_len + c0 : nullptr;
     }
-    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, ImgAcc{}, lr);
+    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, AccG{}, lr);
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                              const float *__restrict__ cz, size_t n) {
@@ -649,7 +699,7 @@ __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotD
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
-    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, ImgAcc{});
+    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, AccG{});
 }
 template <bool EARLY>
 __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
@@ -665,10 +715,10 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__r
     const float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
     if constexpr (EARLY) {
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
@@ -689,11 +739,212 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
     if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
     if constexpr (EARLY) {
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
         velocity_adj_body(g, c, adj, m, md, pc, lr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent backward time loop (option bwd_fuse = 4): ONE launch advances a shot through a whole backward
+// pass.  The grid is occupancy-sized (every workgroup resident at once); a workgroup owns a fixed tile of 64-column row
+// segments (host-built plan, persist_plan.hpp: every tile the same size +- 1, edge segments first) and walks it twice per
+// time step: phase A = the k_bwd_a bodies, phase B = the k_bwd_b bodies -- the same bodies, the same order of operations on
+// every array (Src/libCUFD.cu:545-631), hence bit-identical results.  What fixed ownership buys: the tile's imaging
+// accumulators stay in LDS (template mask LMASK) instead of 8 B of HBM read-modify-write each per cell and step, and there is
+// no grid fill / drain between the 2 x 3999 phases of a pass.
+//
+// Synchronisation between tiles (phases are numbered through the pass; flags[tile] = phases whose EDGE part is complete):
+//   * a stencil reaches at most two rows / one segment column into a neighbouring tile, and everything a phase reads through
+//     a stencil was written in the previous phase -- so a tile may start phase p once every neighbour has finished the edge
+//     part of phase p-1 (their new values are there: RAW; they have read my old ones: WAR).  Edge segments come first in a
+//     phase, the flag is published when the last wave has seen its edge stores acknowledged, and the interior part hides the
+//     latency: the poll at the next phase start normally succeeds at once.  A workgroup barrier per phase orders the tile's own
+//     waves.
+//   * visibility: band = blockIdx % nband is the XCD (checked at run time: all workgroups of a band must report one XCC_ID),
+//     so tiles that exchange halos share an L2 except across the nband - 1 band edges.  Inside a band plain stores are in the
+//     shared L2 once acknowledged; the reader drops its CU's vector L1 once per phase (agent-scope acquire) after the poll.
+//     Segments next to another band (kSegXband) run the bodies with MemAgent: sc1 loads and write-through stores.
+//   * every spin is bounded; a time-out or a placement mismatch raises *err, every workgroup leaves, the host reports it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPersistSpinLimit = 1 << 21;  // polls of ~1 us: about two seconds
+
+// registers sized for 8 waves per SIMD: two workgroups of 16 waves per CU
+template <int LMASK>
+__global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
+    extern __shared__ float lds_dyn[];
+    __shared__ int next_item, edge_done, abort_flag;
+    const ShotDev &s = a.s;
+    const size_t n = a.n;
+    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    const PmlMem m = mem_of(s.bmem, n);
+    const Media md = media_of(a.media, n);
+    const PmlCoef pc = coef_of(a.cz, a.cz + 6 * g.nzc, g.nzc, g.nx);
+    const int band = (int)(blockIdx.x % a.nband);
+    const int tile = band * a.per_band + (int)(blockIdx.x / a.nband);
+    const TileHdr &h = a.hdr[tile];
+    const uint32_t *__restrict__ segs = a.seg + (size_t)tile * (size_t)a.cap;
+    const int nst = h.n_seg, n_edge = h.n_edge, nnb = h.n_nb;
+    const int lane = threadIdx.x & (BX - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    lds_float *const lbase = (lds_float *)lds_dyn;
+    AccT<LMASK> acc{acc_of(s.acc, n), nullptr, a.cap * BX};
+    unsigned int *const my_flag = a.flags + (size_t)tile * 32;
+
+    if (threadIdx.x == 0) {
+        next_item = 0;
+        edge_done = 0;
+        abort_flag = 0;
+        if (!a.nosync) {  // all workgroups of a band on ONE XCD (one L2)?  first comer records its XCC_ID, the others compare
+            const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID, 4 bits
+            const unsigned int seen = atomicCAS(a.band_xcc + band, 0xffffffffu, xcc);
+            if (seen != 0xffffffffu && seen != xcc) {
+                atomicExch(a.err, 2);
+                abort_flag = 1;
+            }
+        }
+    }
+    if (a.census) {  // one-off rendezvous of a new configuration, with THIS kernel's registers and LDS: is every workgroup resident at once?
+        if (threadIdx.x == 0) {
+            unsigned int *arrived = a.band_xcc + 8;
+            atomicAdd(arrived, 1u);
+            int spins = 0;
+            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 18)) {
+                    atomicCAS(a.err, 0, 1);
+                    break;
+                }
+            }
+        }
+        __syncthreads();  // every wave keeps its registers until the count is in: a workgroup whose other waves had left would make room for one that does not fit beside it
+        return;
+    }
+    auto cell_of = [&](uint32_t d) {
+        Cell c;
+        c.z = __builtin_amdgcn_readfirstlane((int)(d & 0xffffu));
+        c.x = (int)((d >> 16) & 0xffu) * BX + lane;
+        c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
+        return c;
+    };
+    // prologue: the tile's accumulators HBM -> LDS (they carry the sum over the shots of the call)
+    if constexpr (LMASK != 0) {
+        for (int j = wave; j < nst; j += nw) {
+            const Cell c = cell_of(segs[j]);
+            lds_float *cell = lbase + j * BX + lane;
+            int r = 0;
+            if constexpr (LMASK & 1) cell[(r++) * acc.stride] = acc.p.lam[c.i];
+            if constexpr (LMASK & 2) cell[(r++) * acc.stride] = acc.p.mu[c.i];
+            if constexpr (LMASK & 4) cell[(r++) * acc.stride] = acc.p.xz[c.i];
+            if constexpr (LMASK & 8) cell[(r++) * acc.stride] = acc.p.a[c.i];
+        }
+    }
+    __syncthreads();
+
+    auto grab = [&]() {  // next work item of the workgroup: (phase, segment) in execution order
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&next_item, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    int w = grab();
+    int local = 0;  // phases done in this launch; a.phase0 + local numbers them through the pass
+    bool dead = abort_flag != 0;
+    for (int it = a.it_hi; it >= a.it_lo && !dead; it--) {
+        Grid gs = g;
+        if (a.img_every > 1) gs.dt_img = (it % a.img_every == 0) ? (float)a.img_every * g.dt : 0.0f;
+        float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
+        const float amp = __fmul_rn(__fmul_rn(a.src_scale, s.stf[it]), g.dt);
+        const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
+        for (int ph = 0; ph < 2 && !dead; ph++, local++) {
+            const unsigned int phase = (unsigned int)(a.phase0 + local);
+            // ---- neighbours through the edge part of the previous phase?  then drop what this CU's L1 still holds of their rows
+            if (wave == 0 && !a.nosync) {
+                bool ok = true;
+                if (phase > 0 && lane < nnb) {
+                    const unsigned int *pf = a.flags + (size_t)h.nb[lane] * 32;
+                    int spins = 0;
+                    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > kPersistSpinLimit ||
+                            ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                }
+                if (!__all(ok)) {
+                    if (lane == 0) {
+                        atomicCAS(a.err, 0, 1);
+                        abort_flag = 1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();  // the tile's own waves: everything of the previous phase is stored; poll and invalidate are done
+            if (abort_flag) {
+                dead = true;
+                break;
+            }
+            const int base = local * nst;
+            bool reported = false;
+            // a wave that has seen its last edge segment of the phase waits for its stores, counts itself in; the last one publishes
+            auto report = [&]() {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (lane == 0) old = atomicAdd(&edge_done, 1);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old + 1 == nw * (local + 1) && lane == 0 && !a.nosync)
+                    __hip_atomic_store(my_flag, phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                reported = true;
+            };
+            for (; w < base + nst; w = grab()) {
+                const int j = w - base;
+                if (j >= n_edge && !reported) report();
+                const uint32_t d = segs[j];
+                const Cell c = cell_of(d);
+                acc.cell = lbase + j * BX + lane;
+                const bool xband = (d & kSegXband) != 0 && !a.nosync;  // wave-uniform
+                if (ph == 0) {
+                    // phase A: reverse-time velocity (+ rho imaging, frame restore) + adjoint stress of the previous step
+                    if (xband) {
+                        velocity_body<false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+                        stress_adj_body<MemAgent>(gs, c, adj, m, md, pc);
+                    } else {
+                        velocity_body<false>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+                        stress_adj_body(gs, c, adj, m, md, pc);
+                    }
+                } else {
+                    // phase B: source_grad + reverse-time stress (+ lambda/mu imaging, frame restore) + adjoint velocity + injection
+                    if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
+                    if (xband) {
+                        stress_body<false, false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+                        velocity_adj_body<MemAgent>(gs, c, adj, m, md, pc, lr);
+                    } else {
+                        stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+                        velocity_adj_body(gs, c, adj, m, md, pc, lr);
+                    }
+                }
+            }
+            if (!reported) report();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the phase are complete before the next barrier
+        }
+    }
+    __syncthreads();
+
+    // epilogue: LDS -> HBM
+    if constexpr (LMASK != 0) {
+        for (int j = wave; j < nst; j += nw) {
+            const Cell c = cell_of(segs[j]);
+            lds_float *cell = lbase + j * BX + lane;
+            int r = 0;
+            if constexpr (LMASK & 1) acc.p.lam[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 2) acc.p.mu[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 4) acc.p.xz[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 8) acc.p.a[c.i] = cell[(r++) * acc.stride];
+        }
     }
 }
 
@@ -932,7 +1183,7 @@ struct OptField {
 };
 const OptField kOptFields[] = {
     {"bz", &KernelOptions::bz, 1, 16},           {"xcd_remap", &KernelOptions::xcd_remap, 0, 1},
-    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 2}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
+    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 4}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
     {"pair_fwd", &KernelOptions::pair_fwd, 0, 1}, {"fwd_lanes", &KernelOptions::fwd_lanes, 1, 4},
     {"early", &KernelOptions::early, 0, 3},       {"rho_fly", &KernelOptions::rho_fly, 0, 3},
     {"amu_fly", &KernelOptions::amu_fly, 0, 3},   {"rk_lazy", &KernelOptions::rk_lazy, 0, 1},
@@ -942,6 +1193,8 @@ const OptField kOptFields[] = {
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
+    {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
+    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
 };
 }  // namespace
 
@@ -958,7 +1211,7 @@ int set_kernel_option(const char *name, int value) {
     std::lock_guard<std::mutex> lock(g_opt_mu);
     for (const OptField &f : kOptFields)
         if (n == f.name) {
-            if (value < f.lo || value > f.hi || (n == "bwd_fuse" && value == 1)) return -1;
+            if (value < f.lo || value > f.hi || (n == "bwd_fuse" && (value == 1 || value == 3))) return -1;
             g_opt.*(f.field) = value;
             return 0;
         }
@@ -1072,6 +1325,44 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
     else
         hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t, (z_src << 16) | x_src, src_amp, src_rxz,
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
+}
+
+static void (*persist_kernel(int lmask))(Grid, const PersistArgs) {
+    switch (lmask) {
+        case 0: return k_bwd_persist<0>;
+        case 1: return k_bwd_persist<1>;
+        case 3: return k_bwd_persist<3>;
+        case 7: return k_bwd_persist<7>;
+        case 15: return k_bwd_persist<15>;
+        default: return nullptr;
+    }
+}
+
+// 0, or why this grid cannot run the persistent loop (never launches a grid that would not be resident at once: its tiles wait for
+// each other)
+static int persist_config_ok(const void *k, int nwg, int threads, size_t lds_bytes) {
+    if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds_bytes) != hipSuccess) return -3;
+    int dev = 0, ncu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (per_cu * ncu < nwg) return -4;
+    return 0;
+}
+
+int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
+                       size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const Grid g = tiled(g0, o, 1);
+    auto k = persist_kernel(lmask);
+    if (!k) return -1;
+    const int rc = persist_config_ok((const void *)k, nwg, threads, lds_bytes);
+    if (rc) return rc;
+    if (ev_start)
+        hipExtLaunchKernelGGL(k, dim3(nwg), dim3(threads), lds_bytes, st, ev_start, ev_stop, 0, g, args);
+    else
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(threads), lds_bytes, st, g, args);
+    return 0;
 }
 
 __global__ void k_add_inplace(float *__restrict__ a, const float *__restrict__ b, size_t n) {

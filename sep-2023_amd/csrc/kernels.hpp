@@ -11,7 +11,8 @@ namespace sepfwi {
 struct KernelOptions {
     int bz = 2;           // waves (rows) per block of the field kernels
     int xcd_remap = 1;    // 1: each XCD gets a contiguous band of tiles
-    int bwd_fuse = 2;     // backward step: 0 the reference's four kernels (+ k_inject), 2 cross-chain pairs k_bwd_a / k_bwd_b
+    int bwd_fuse = 4;     // backward step: 0 the reference's four kernels (+ k_inject), 2 cross-chain pairs k_bwd_a / k_bwd_b, 4 the
+                          // persistent time loop where the grid and the survey allow it (else 2)
     int line_fuse = 1;    // 1: line receivers are sampled / injected inside the field kernels
     int pair_fwd = 1;     // 1: forward passes of several shots run concurrently (one stream each, or one batched launch)
     int fwd_lanes = 3;    // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
@@ -26,6 +27,12 @@ struct KernelOptions {
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
     int obs_cache_mb = 0; // HBM budget [MB] of the observed-data store (0: unlimited; a parameter-file key of the same name wins)
+    // persistent backward time loop (bwd_fuse = 4; kernels.hip k_bwd_persist)
+    int pk_lmask = 16;    //   imaging accumulators kept in LDS: bit 0 lam, 1 mu, 2 xz, 3 a (16: as many as fit, in that order)
+    int pk_wpc = 2;       //   workgroups (16 waves each) per CU
+    int pk_px = 3;        //   strip width of the tiling in row segments (persist_plan.hpp)
+    int pk_waves = 16;    //   waves per workgroup
+    int pk_nosync = 0;    //   1: no synchronisation between tiles -- WRONG RESULTS, timing experiments only
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)
 };
@@ -56,6 +63,10 @@ void launch_bwd_a_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it);
 void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// persistent backward time loop (tiles: persist_plan.hpp): the launch (0, or < 0 when the grid cannot be resident at once / the LDS
+// does not fit).  args.census: the one-off rendezvous of a new configuration (every workgroup resident at once?  one XCD per band?)
+int launch_bwd_persist(hipStream_t st, const Grid &g, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
+                       size_t lds_bytes, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);
 void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int *rec_idx, float *d_pr, float *d_vx,
                    float *d_vz, float *d_ett, int comps, const float *sens = nullptr);

@@ -1,0 +1,43 @@
+// persist_plan.hpp -- host-side tiling of the grid for the persistent backward time loop (kernels.hip, k_bwd_persist).
+//
+// The unit of work is a ROW SEGMENT: 64 consecutive columns of one row (one wave, one 256-B line per array).  The grid's
+// segments are dealt to `nwg` workgroups that stay resident for a whole backward pass; a workgroup owns the same segments in
+// every time step (its imaging accumulators live in LDS).  Layout: `nband` bands of rows (one per XCD, so that tiles that
+// exchange halos share an L2 except across the nband - 1 band edges); inside a band the segments are ordered strip by strip
+// (strips `strip_w` segments wide, walked top-down / bottom-up alternately) and that sequence is cut into equal runs, one per
+// workgroup -- every tile has the same number of segments +- 1 whatever the grid size.
+//
+// A segment is an EDGE segment when a stencil centred in it reaches a segment of another tile (rows z +- 1, z +- 2 of the same
+// segment column, or the two neighbouring segment columns of the same row); edge segments are processed first in every phase
+// and their completion is what a tile publishes to its neighbours.  XBAND marks edge segments whose partner lies in another
+// band (another XCD's L2).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sepfwi {
+
+constexpr int kPlanMaxNb = 16;
+constexpr uint32_t kSegEdge = 1u << 24, kSegXband = 1u << 25;
+
+struct TileHdr {  // device-readable
+    int n_edge, n_seg, n_nb;
+    int nb[kPlanMaxNb];  // tiles this tile exchanges halos with
+    int pad[13];         // 128 bytes: one header per cache line
+};
+static_assert(sizeof(TileHdr) == 128, "TileHdr is one 128-byte line");
+
+struct PersistPlan {
+    int nwg = 0, nband = 0, per_band = 0, cap = 0;  // cap: slots per tile in `seg` (>= the largest tile)
+    int nzc = 0, nseg = 0, strip_w = 0;
+    std::vector<uint32_t> seg;  // [nwg][cap]: z | segment column << 16 | flags; edge segments first
+    std::vector<TileHdr> hdr;   // [nwg]
+    std::vector<int> owner;     // [nzc][nseg] -> tile
+};
+
+// Builds the plan; returns an empty string, or why the grid cannot be tiled this way (e.g. a tile with more than kPlanMaxNb
+// neighbours).  Rows [0, nzc) x segment columns [0, nseg).
+std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true);
+
+}  // namespace sepfwi

@@ -223,6 +223,11 @@ Session::~Session() {
         if (L.join) (void)hipEventDestroy(L.join);
     }
     obs_.reset();
+    if (pk_.d_seg) (void)hipFree(pk_.d_seg);
+    if (pk_.d_hdr) (void)hipFree(pk_.d_hdr);
+    if (pk_.d_sync) (void)hipFree(pk_.d_sync);
+    if (pk_.d_stf) (void)hipFree(pk_.d_stf);
+    if (pk_.h_err) (void)hipHostFree(pk_.h_err);
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
     if (stf_grad_) (void)hipFree(stf_grad_);
@@ -361,6 +366,7 @@ void Session::stats(sepfwi_stats *out) const {
     out->obs_device_bytes = obs_->device_bytes();
     out->obs_host_bytes = obs_->host_bytes();
     out->obs_evictions = obs_->evictions();
+    out->persist_steps = persist_steps_;
     out->probe_kernel_us = probe_calls_ ? probe_us_ / (double)probe_calls_ : 0.0;
     out->probe_calls = probe_calls_;
     // one forward pass = N_c*(nSteps-1); fwd+adj = 3x (forward, reconstruction, adjoint)

@@ -16,6 +16,7 @@
 #include "fwi_types.hpp"
 #include "kernels.hpp"
 #include "obs_store.hpp"
+#include "persist_plan.hpp"
 
 namespace sepfwi {
 
@@ -102,6 +103,9 @@ class Session {
     void backward_init(const BwdLane &L);
     void backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it);
     void backward(Call &c, const ShotCtx &x);
+    // the same pass as ONE persistent launch (option bwd_fuse = 4; kernels.hip k_bwd_persist)
+    bool persist_ready(const Call &c, const ShotCtx &x);
+    void backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L);
     hipEvent_t *probe_pair(Call &c, int it);
     void collect_probes(Call &c);
     // the two schedules of a call's shots
@@ -166,6 +170,20 @@ class Session {
     PmlCoef pc_{};
     ImgAcc acc_{};
     std::unique_ptr<ObservedStore> obs_;
+    // persistent backward time loop: the tiling in use, its device copy, synchronisation words, what the census of the grid said
+    struct Persist {
+        PersistPlan plan;
+        uint32_t *d_seg = nullptr;
+        TileHdr *d_hdr = nullptr;
+        unsigned int *d_sync = nullptr;  // [nwg x 32 flag words | 8 band XCC ids | arrived | err]
+        float *d_stf = nullptr;
+        int *h_err = nullptr;            // pinned
+        int nwg = 0, threads = 0, lmask = 0, wpc = 0, strip_w = 0;
+        size_t lds_bytes = 0;
+        int state = -1;                  // -1 not examined for this configuration, 0 the two-launch step is used, 1 ready
+        std::string why;                 // when state == 0
+    } pk_;
+    long long persist_steps_ = 0;
 
     double fwd_ms_ = 0, bwd_ms_ = 0, total_ms_ = 0;
     long long fwd_steps_ = 0, bwd_steps_ = 0, launches_ = 0;

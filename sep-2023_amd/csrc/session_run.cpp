@@ -311,7 +311,7 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
     }
     Grid gs = g;  // this step's imaging weight (option img_every)
     if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-    if (opt.bwd_fuse == 2) {
+    if (opt.bwd_fuse != 0) {
         hipEvent_t *ev = probe_pair(c, it);
         launch_bwd_a(L.s, gs, opt, x.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
         launch_bwd_b(L.s, gs, opt, x.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, ev ? ev[0] : nullptr,
@@ -328,12 +328,156 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
     }
 }
 
+// ---- the backward pass of one shot as ONE persistent launch ----------------------------------------------------------------
+// Can this call's configuration run k_bwd_persist?  Decided once per (workgroups per CU, strip width, LDS mask): the tiling is
+// built and uploaded, the LDS-resident accumulators are chosen to fit, and a census launch checks that the whole grid is resident at
+// once and that the workgroups of a band share one XCD.  Otherwise (and for shots whose receivers are not a fused line of
+// channels, which need k_inject between the phases) the two-launch step runs.
+bool Session::persist_ready(const Call &c, const ShotCtx &x) {
+    const KernelOptions &opt = c.opt;
+    if (opt.bwd_fuse != 4) return false;
+    if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
+    Persist &k = pk_;
+    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) return k.state == 1;
+    k.state = 0;
+    k.wpc = opt.pk_wpc;
+    k.strip_w = opt.pk_px;
+    int ncu = 0;
+    HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, gpu_id_));
+    const int nband = 8, nseg = (g_.nx + 63) / 64;
+    k.nwg = (ncu / nband) * nband * opt.pk_wpc;
+    k.threads = 64 * opt.pk_waves;
+    if (k.nwg <= 0 || (long long)g_.nzc * nseg < 4LL * k.nwg) {  // tiles of a handful of segments: the per-step launches (batched) are the better form
+        k.why = "grid too small for " + std::to_string(k.nwg) + " tiles";
+        return false;
+    }
+    k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan);
+    if (!k.why.empty()) return false;
+    // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a in that order; b stays in HBM)
+    const size_t lds_cu = 160 * 1024, per_wg = lds_cu / (size_t)opt.pk_wpc - 256;
+    const int masks[5] = {15, 7, 3, 1, 0};
+    k.lmask = -1;
+    for (int mk : masks) {
+        if (opt.pk_lmask != 16 && mk != opt.pk_lmask) continue;
+        const size_t need = (size_t)__builtin_popcount(mk) * (size_t)k.plan.cap * 64 * sizeof(float);
+        if (need <= per_wg) {
+            k.lmask = mk;
+            k.lds_bytes = need;
+            break;
+        }
+    }
+    if (k.lmask < 0) {
+        k.why = "LDS accumulators do not fit";
+        return false;
+    }
+    auto refree = [](auto *&p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    refree(k.d_seg);
+    refree(k.d_hdr);
+    refree(k.d_sync);
+    const size_t sync_words = (size_t)k.nwg * 32 + 16;
+    HIP_OK(dev_malloc((void **)&k.d_seg, k.plan.seg.size() * sizeof(uint32_t)));
+    HIP_OK(dev_malloc((void **)&k.d_hdr, k.plan.hdr.size() * sizeof(TileHdr)));
+    HIP_OK(dev_malloc((void **)&k.d_sync, sync_words * sizeof(unsigned int)));
+    if (!k.d_stf) HIP_OK(dev_malloc((void **)&k.d_stf, (size_t)par_.nSteps * sizeof(float)));
+    if (!k.h_err) HIP_OK(hipHostMalloc((void **)&k.h_err, 4 * sizeof(int), hipHostMallocDefault));
+    HIP_OK(hipMemcpy(k.d_seg, k.plan.seg.data(), k.plan.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(k.d_hdr, k.plan.hdr.data(), k.plan.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
+    // census: residency rendezvous + one XCD per band -- a launch of the loop's own kernel (its registers, its LDS) without time steps
+    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
+    int *err = (int *)(band_xcc + 9);
+    hipStream_t st = c.st;
+    HIP_OK(hipMemsetAsync(k.d_sync, 0, sync_words * sizeof(unsigned int), st));
+    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
+    PersistArgs a{};
+    a.nband = nband;
+    a.per_band = k.plan.per_band;
+    a.cap = k.plan.cap;
+    a.seg = k.d_seg;
+    a.hdr = k.d_hdr;
+    a.flags = k.d_sync;
+    a.band_xcc = band_xcc;
+    a.err = err;
+    a.census = 1;
+    a.it_hi = -1;
+    const int rc = launch_bwd_persist(st, g_, opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
+    if (rc != 0) {
+        k.why = "the grid of " + std::to_string(k.nwg) + " workgroups is not resident at once (code " + std::to_string(rc) + ")";
+        return false;
+    }
+    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (k.h_err[0] != 0) {
+        k.why = k.h_err[0] == 2 ? "workgroups of one band run on several XCDs" : "census rendezvous timed out";
+        return false;
+    }
+    k.state = 1;
+    k.why.clear();
+    return true;
+}
+
+void Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
+    Persist &k = pk_;
+    const int nSteps = par_.nSteps;
+    hipStream_t st = L.s;
+    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
+    int *err = (int *)(band_xcc + 9);
+    HIP_OK(hipMemsetAsync(k.d_sync, 0, ((size_t)k.nwg * 32 + 16) * sizeof(unsigned int), st));
+    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
+    HIP_OK(hipMemcpyAsync(k.d_stf, x.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, st));
+    PersistArgs a{};
+    ShotDev &d = a.s;
+    d.fields = x.state;
+    d.frame = x.frame;
+    d.stf = k.d_stf;
+    d.bmem = L.bm.dvz_dz;
+    d.adj = L.adj.vz;
+    d.acc = L.acc.lam;
+    d.res = x.res;
+    d.stf_grad = stf_grad_ + (size_t)x.is * nSteps;
+    d.z_src = x.sh->z_src;
+    d.x_src = x.sh->x_src;
+    d.lr_z = x.line.z;
+    d.lr_x0 = x.line.x0;
+    d.lr_n = x.line.n;
+    d.nrec = x.nrec;
+    d.src_rxz = (float)x.sh->src_rxz;
+    a.media = md_.lam;
+    a.cz = pc_.a_z;
+    a.n = cells_;
+    a.it_hi = nSteps - 2;
+    a.it_lo = 0;
+    a.src_scale = c.src_scale;
+    a.img_every = c.opt.img_every;
+    a.nband = k.plan.nband;
+    a.per_band = k.plan.per_band;
+    a.cap = k.plan.cap;
+    a.seg = k.d_seg;
+    a.hdr = k.d_hdr;
+    a.flags = k.d_sync;
+    a.band_xcc = band_xcc;
+    a.err = err;
+    a.phase0 = 0;
+    a.nosync = c.opt.pk_nosync;
+    const int rc = launch_bwd_persist(st, g_, c.opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
+    if (rc != 0) throw HipError("persistent backward loop could not be launched (code " + std::to_string(rc) + ")");
+    launches_++;
+    persist_steps_ += (long long)(nSteps - 1);
+    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));  // read after the pass's synchronisation (backward)
+}
+
 void Session::backward(Call &c, const ShotCtx &x) {
     hipStream_t st = c.st;
     const BwdLane L{st, mem_, adj_, acc_};
+    const bool persistent = persist_ready(c, x);
     HIP_OK(hipEventRecord(ev_[2], st));
     backward_init(L);
-    for (int it = par_.nSteps - 2; it >= 0; it--) backward_step(c, x, L, it);
+    if (persistent)
+        backward_persistent(c, x, L);
+    else
+        for (int it = par_.nSteps - 2; it >= 0; it--) backward_step(c, x, L, it);
     HIP_OK(hipEventRecord(ev_[3], st));
     bwd_steps_ += (long long)(par_.nSteps - 1);
     HIP_OK(hipStreamSynchronize(st));
@@ -341,6 +485,26 @@ void Session::backward(Call &c, const ShotCtx &x) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     bwd_ms_ += ms;
+    if (persistent && pk_.h_err[0] != 0) {
+        // where the tiles stood: flags[tile] = phases whose edge part is complete
+        std::vector<unsigned int> fl((size_t)pk_.nwg * 32);
+        HIP_OK(hipMemcpy(fl.data(), pk_.d_sync, fl.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        unsigned int lo = ~0u, hi = 0;
+        int t_lo = 0, never = 0;
+        for (int t = 0; t < pk_.nwg; t++) {
+            const unsigned int v = fl[(size_t)t * 32];
+            if (v < lo) { lo = v; t_lo = t; }
+            hi = std::max(hi, v);
+            never += v == 0;
+        }
+        pk_.state = 0;  // this session goes back to the two-launch step
+        pk_.why = "a pass failed";
+        throw HipError(std::string("persistent backward loop: ") +
+                       (pk_.h_err[0] == 2 ? "workgroups of one band ran on several XCDs" : "a tile waited for its neighbour beyond the time limit") +
+                       " (results discarded; tiles reached phases " + std::to_string(lo) + " ... " + std::to_string(hi) + " of " +
+                       std::to_string(2 * (par_.nSteps - 1)) + ", slowest tile " + std::to_string(t_lo) + ", " + std::to_string(never) + " of " +
+                       std::to_string(pk_.nwg) + " never published)");
+    }
 }
 
 // ---- stream schedule: up to fwd_lanes forward passes side by side (their kernel-boundary gaps and tails fill each other:
@@ -551,7 +715,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     fwd_ms_ = bwd_ms_ = 0.0;
     probe_us_ = 0.0;
     probe_calls_ = 0;
-    fwd_steps_ = bwd_steps_ = 0;
+    fwd_steps_ = bwd_steps_ = persist_steps_ = 0;
     for (int i = 0; i < group_size; i++) {
         const int id = shot_ids[i];
         if (id < 0 || id >= (int)survey_.shots.size() || !survey_.shots[id].present)
@@ -574,7 +738,7 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     // backward passes fit (2000x1000) the stream schedule runs the backward passes one by one.
     const double arr_mb = (double)cells_ * sizeof(float) / 1.0e6, budget = (double)c.opt.batch_mb;
     int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
-    const bool batched = c.opt.bwd_fuse == 2 && group_size >= 1 &&
+    const bool batched = c.opt.bwd_fuse != 0 && group_size >= 1 &&
                          (c.opt.batch == 1 || (c.opt.batch == 2 && (c.with_adj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
     last_batched_ = batched;
     if (batched) {

@@ -12,8 +12,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
-SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "obs_store.cpp", "host_checks.cpp", "config.cpp", "capi.cpp"]
-HEADERS = ["kernels.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "config.cpp", "capi.cpp"]
+HEADERS = ["kernels.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
 _lib = None
@@ -25,7 +25,7 @@ class Stats(C.Structure):
                 ("cell_updates", C.c_double), ("fwd_steps", C.c_longlong), ("bwd_steps", C.c_longlong),
                 ("launches", C.c_longlong), ("device_bytes", C.c_longlong), ("n_c", C.c_int),
                 ("probe_kernel_us", C.c_double), ("probe_calls", C.c_longlong),
-                ("obs_device_bytes", C.c_longlong), ("obs_host_bytes", C.c_longlong), ("obs_evictions", C.c_longlong)]
+                ("obs_device_bytes", C.c_longlong), ("obs_host_bytes", C.c_longlong), ("obs_evictions", C.c_longlong), ("persist_steps", C.c_longlong)]
 
 
 def needs_build() -> bool:
