@@ -104,6 +104,8 @@ struct ShotDev {
     float src_rxz;
 };
 
+constexpr unsigned int kPersistGo = 1, kPersistAbortResidency = 2, kPersistAbortPlacement = 3;  // start rendezvous of k_bwd_persist
+
 // Argument block of the persistent backward time loop (k_bwd_persist), passed BY VALUE: pointers that arrive in the kernel-argument
 // segment are known to be global, so the bodies compile to global_load / global_store with graded waits (through a pointer to this
 // block they were flat accesses with full drains: profiles/EXPERIMENTS.md #35k).  One shot, time steps it_hi ... it_lo.
@@ -119,10 +121,10 @@ struct PersistArgs {
     const uint32_t *seg;  // [tiles][cap] segment descriptors (persist_plan.hpp)
     const struct TileHdr *hdr;
     unsigned int *flags;     // [tiles] x 32 words (one 128-B line each): phases of the pass whose edge part is complete
-    unsigned int *band_xcc;  // [nband]: XCC_ID the band's workgroups run on (0xffffffff before the first reports); [8]: census counter
-    int *err;                // 0, 1 a wait timed out, 2 a band is spread over several XCDs
+    unsigned int *band_xcc;  // [nband]: XCC_ID the band's workgroups run on (0xffffffff before the first reports); [8] workgroups arrived,
+                             // [9] the start rendezvous' decision (kPersist*)
+    int *err;                // 0, 1 a wait inside the pass timed out
     int phase0;              // phases of the pass done by earlier launches
-    int census;              // 1: no time steps -- every workgroup counts itself in at band_xcc[8] and waits (bounded) for all the others
     int nosync;              // timing experiments only: no waits, no flags, no agent-scope accesses (results wrong)
 };
 

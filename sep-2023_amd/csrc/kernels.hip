@@ -767,15 +767,18 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
 //     so tiles that exchange halos share an L2 except across the nband - 1 band edges.  Inside a band plain stores are in the
 //     shared L2 once acknowledged; the reader drops its CU's vector L1 once per phase (agent-scope acquire) after the poll.
 //     Segments next to another band (kSegXband) run the bodies with MemAgent: sc1 loads and write-through stores.
-//   * every spin is bounded; a time-out or a placement mismatch raises *err, every workgroup leaves, the host reports it.
+//   * the pass starts with a rendezvous of the whole grid (below): if the grid is not resident at once, or a band is spread over
+//     several XCDs, every workgroup leaves before anything is touched and the host runs the two-launch step instead.
+//   * every spin is bounded; a time-out later in the pass raises *err, every workgroup leaves, the host reports it.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPersistSpinLimit = 1 << 21;  // polls of ~1 us: about two seconds
+constexpr int kPersistSpinLimit = 1 << 21;   // polls of ~1 us: about two seconds (never reached once the start rendezvous has passed)
+constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 
 // registers sized for 8 waves per SIMD: two workgroups of 16 waves per CU
 template <int LMASK>
 __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
     extern __shared__ float lds_dyn[];
-    __shared__ int next_item, edge_done, abort_flag;
+    __shared__ int next_item, edge_done, abort_flag, start_verdict;
     const ShotDev &s = a.s;
     const size_t n = a.n;
     const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
@@ -793,35 +796,31 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
     AccT<LMASK> acc{acc_of(s.acc, n), nullptr, a.cap * BX};
     unsigned int *const my_flag = a.flags + (size_t)tile * 32;
 
+    // ---- start rendezvous: nothing is touched before EVERY workgroup of the grid is known to be resident (they wait for each
+    // other all pass long and cannot be pre-empted) and every band is known to sit on one XCD.  ONE word decides for all:
+    // the last arriver votes GO, a workgroup that has waited too long (the GPU is busy with something else: another process'
+    // kernels, another persistent grid) votes ABORT; whichever compare-and-swap comes first stands, also for late arrivers.
     if (threadIdx.x == 0) {
         next_item = 0;
         edge_done = 0;
         abort_flag = 0;
-        if (!a.nosync) {  // all workgroups of a band on ONE XCD (one L2)?  first comer records its XCC_ID, the others compare
+        unsigned int verdict = kPersistGo;
+        if (!a.nosync) {
+            unsigned int *arrived = a.band_xcc + 8, *decision = a.band_xcc + 9;
             const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID, 4 bits
-            const unsigned int seen = atomicCAS(a.band_xcc + band, 0xffffffffu, xcc);
-            if (seen != 0xffffffffu && seen != xcc) {
-                atomicExch(a.err, 2);
-                abort_flag = 1;
-            }
-        }
-    }
-    if (a.census) {  // one-off rendezvous of a new configuration, with THIS kernel's registers and LDS: is every workgroup resident at once?
-        if (threadIdx.x == 0) {
-            unsigned int *arrived = a.band_xcc + 8;
-            atomicAdd(arrived, 1u);
+            const unsigned int seen = atomicCAS(a.band_xcc + band, 0xffffffffu, xcc);  // first comer records, the others compare
+            if (seen != 0xffffffffu && seen != xcc) atomicCAS(decision, 0u, kPersistAbortPlacement);
+            if (atomicAdd(arrived, 1u) == gridDim.x - 1) atomicCAS(decision, 0u, kPersistGo);
             int spins = 0;
-            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            while ((verdict = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 18)) {
-                    atomicCAS(a.err, 0, 1);
-                    break;
-                }
+                if (++spins > kPersistStartLimit) atomicCAS(decision, 0u, kPersistAbortResidency);
             }
         }
-        __syncthreads();  // every wave keeps its registers until the count is in: a workgroup whose other waves had left would make room for one that does not fit beside it
-        return;
+        start_verdict = (int)verdict;
     }
+    __syncthreads();  // (all waves keep their registers meanwhile: a workgroup reduced to one wave would make room for one that does not fit)
+    if (start_verdict != (int)kPersistGo) return;
     auto cell_of = [&](uint32_t d) {
         Cell c;
         c.z = __builtin_amdgcn_readfirstlane((int)(d & 0xffffu));

@@ -182,6 +182,7 @@ class Session {
         size_t lds_bytes = 0;
         int state = -1;                  // -1 not examined for this configuration, 0 the two-launch step is used, 1 ready
         std::string why;                 // when state == 0
+        int retry_in = 0, aborts = 0;    // passes until the loop is tried again after a start rendezvous that failed; how often it did
     } pk_;
     long long persist_steps_ = 0;
 

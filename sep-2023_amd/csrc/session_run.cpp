@@ -329,16 +329,20 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
 }
 
 // ---- the backward pass of one shot as ONE persistent launch ----------------------------------------------------------------
-// Can this call's configuration run k_bwd_persist?  Decided once per (workgroups per CU, strip width, LDS mask): the tiling is
-// built and uploaded, the LDS-resident accumulators are chosen to fit, and a census launch checks that the whole grid is resident at
-// once and that the workgroups of a band share one XCD.  Otherwise (and for shots whose receivers are not a fused line of
-// channels, which need k_inject between the phases) the two-launch step runs.
+// Can this call's configuration run k_bwd_persist?  Decided once per (workgroups per CU, waves, strip width, LDS mask): the tiling
+// is built and uploaded and the LDS-resident accumulators are chosen to fit.  Whether the grid really is resident at once (and every
+// band on one XCD) is decided by the start rendezvous of each pass (backward): a pass that does not start leaves everything
+// untouched, runs as per-step launches, and switches the session back to them.  Shots whose receivers are not a fused line of
+// channels need k_inject between the two halves of a step and never take the loop.
 bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     const KernelOptions &opt = c.opt;
     if (opt.bwd_fuse != 4) return false;
     if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
     Persist &k = pk_;
-    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) return k.state == 1;
+    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
+        if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
+        return k.state == 1;
+    }
     k.state = 0;
     k.wpc = opt.pk_wpc;
     k.strip_w = opt.pk_px;
@@ -385,34 +389,6 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     if (!k.h_err) HIP_OK(hipHostMalloc((void **)&k.h_err, 4 * sizeof(int), hipHostMallocDefault));
     HIP_OK(hipMemcpy(k.d_seg, k.plan.seg.data(), k.plan.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(k.d_hdr, k.plan.hdr.data(), k.plan.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
-    // census: residency rendezvous + one XCD per band -- a launch of the loop's own kernel (its registers, its LDS) without time steps
-    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
-    int *err = (int *)(band_xcc + 9);
-    hipStream_t st = c.st;
-    HIP_OK(hipMemsetAsync(k.d_sync, 0, sync_words * sizeof(unsigned int), st));
-    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
-    PersistArgs a{};
-    a.nband = nband;
-    a.per_band = k.plan.per_band;
-    a.cap = k.plan.cap;
-    a.seg = k.d_seg;
-    a.hdr = k.d_hdr;
-    a.flags = k.d_sync;
-    a.band_xcc = band_xcc;
-    a.err = err;
-    a.census = 1;
-    a.it_hi = -1;
-    const int rc = launch_bwd_persist(st, g_, opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
-    if (rc != 0) {
-        k.why = "the grid of " + std::to_string(k.nwg) + " workgroups is not resident at once (code " + std::to_string(rc) + ")";
-        return false;
-    }
-    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    if (k.h_err[0] != 0) {
-        k.why = k.h_err[0] == 2 ? "workgroups of one band run on several XCDs" : "census rendezvous timed out";
-        return false;
-    }
     k.state = 1;
     k.why.clear();
     return true;
@@ -423,7 +399,7 @@ void Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     const int nSteps = par_.nSteps;
     hipStream_t st = L.s;
     unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
-    int *err = (int *)(band_xcc + 9);
+    int *err = (int *)(band_xcc + 10);
     HIP_OK(hipMemsetAsync(k.d_sync, 0, ((size_t)k.nwg * 32 + 16) * sizeof(unsigned int), st));
     HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
     HIP_OK(hipMemcpyAsync(k.d_stf, x.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, st));
@@ -465,7 +441,8 @@ void Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     if (rc != 0) throw HipError("persistent backward loop could not be launched (code " + std::to_string(rc) + ")");
     launches_++;
     persist_steps_ += (long long)(nSteps - 1);
-    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));  // read after the pass's synchronisation (backward)
+    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));  // both read after the pass's synchronisation (backward)
+    HIP_OK(hipMemcpyAsync(k.h_err + 1, band_xcc + 9, sizeof(int), hipMemcpyDeviceToHost, st));
 }
 
 void Session::backward(Call &c, const ShotCtx &x) {
@@ -474,10 +451,22 @@ void Session::backward(Call &c, const ShotCtx &x) {
     const bool persistent = persist_ready(c, x);
     HIP_OK(hipEventRecord(ev_[2], st));
     backward_init(L);
-    if (persistent)
+    if (persistent) {
         backward_persistent(c, x, L);
-    else
+        HIP_OK(hipStreamSynchronize(st));
+        if (pk_.h_err[1] != (int)kPersistGo) {  // the loop did not start (nothing touched): this pass, and the session from now on, as per-step launches
+            pk_.state = 0;
+            const bool busy = pk_.h_err[1] != (int)kPersistAbortPlacement;
+            pk_.why = busy ? "the grid was not resident at once (GPU busy, or the configuration does not fit)" : "workgroups of one band run on several XCDs";
+            pk_.retry_in = busy ? (pk_.aborts < 3 ? 16 : 0) : 0;  // transient contention: another try after 16 passes, three times at most
+            if (pk_.aborts++ == 0)
+                fprintf(stderr, "sepfwi: persistent backward loop not started (%s); this pass runs as per-step launches\n", pk_.why.c_str());
+            persist_steps_ -= (long long)(par_.nSteps - 1);
+            for (int it = par_.nSteps - 2; it >= 0; it--) backward_step(c, x, L, it);
+        }
+    } else {
         for (int it = par_.nSteps - 2; it >= 0; it--) backward_step(c, x, L, it);
+    }
     HIP_OK(hipEventRecord(ev_[3], st));
     bwd_steps_ += (long long)(par_.nSteps - 1);
     HIP_OK(hipStreamSynchronize(st));
@@ -499,8 +488,7 @@ void Session::backward(Call &c, const ShotCtx &x) {
         }
         pk_.state = 0;  // this session goes back to the two-launch step
         pk_.why = "a pass failed";
-        throw HipError(std::string("persistent backward loop: ") +
-                       (pk_.h_err[0] == 2 ? "workgroups of one band ran on several XCDs" : "a tile waited for its neighbour beyond the time limit") +
+        throw HipError(std::string("persistent backward loop: a tile waited for its neighbour beyond the time limit") +
                        " (results discarded; tiles reached phases " + std::to_string(lo) + " ... " + std::to_string(hi) + " of " +
                        std::to_string(2 * (par_.nSteps - 1)) + ", slowest tile " + std::to_string(t_lo) + ", " + std::to_string(never) + " of " +
                        std::to_string(pk_.nwg) + " never published)");

@@ -109,7 +109,14 @@ def test_headline_2000x1000x4000_reconstruction_returns_to_zero(tmp_path, hip_op
     assert end_v > 1e-3 * peak_v
     m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
     st = hip_ops.stats(pb["para_fname"], 0)
-    assert st["fwd_steps"] == nS - 1 and st["bwd_steps"] == nS - 1
+    assert st["fwd_steps"] == nS - 1 and st["bwd_steps"] == nS - 1 and st["persist_steps"] == nS - 1
+    # ... and the two-launch step gives the same bits at the full size (3999 time steps x 512 tiles x 2 phases of flag hand-offs)
+    with P.kernel_options(bwd_fuse=2):
+        ref2 = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+        assert hip_ops.stats(pb["para_fname"], 0)["persist_steps"] == 0
+    for a_, b_ in zip((m, gL, gM, gD, gS), ref2):
+        assert torch.equal(a_, b_)
+    hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])      # (leave the persistent loop's final state for the field checks below)
     assert float(m) > 0 and all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in (gL, gM, gD))
     worst = {}
     for which, name in enumerate(("vz", "vx", "szz", "sxx", "sxz")):
@@ -300,6 +307,7 @@ def test_headline_full_size_matches_oracle(tmp_path, hip_ops):
     assert P.rel_l2(obs["ett"][ch][:, late], G["obs_ett"][:, late]) <= 1e-4
     # gradient of the initial model
     m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    assert hip_ops.stats(pb["para_fname"], 0)["persist_steps"] == nS - 1        # at this size the backward pass IS the persistent loop (default)
     e_m = abs(float(m) - float(G["misfit"])) / float(G["misfit"])
     out = {"misfit": e_m}
     assert e_m <= 1e-4, (float(m), float(G["misfit"]))
@@ -355,6 +363,7 @@ def test_headline_32_shots_match_oracle(tmp_path, hip_ops):
                 os.remove(os.path.join(data_dir, "Shot_%s%d.bin" % (c, sid)))
     ids = torch.arange(n_shots, dtype=torch.int32)
     m, gL, gM, gD, gS = hip_ops.backward(lam, mu, den, pb["Stf"], 1, ids, pb["para_fname"])
+    assert hip_ops.stats(pb["para_fname"], 0)["persist_steps"] == n_shots * (nS - 1)   # every one of the 32 backward passes in the persistent loop
     out = {"misfit": abs(float(m) - float(G["misfit"])) / float(G["misfit"])}
     assert out["misfit"] <= 1e-4, (float(m), float(G["misfit"]))
     d = int(G["decim"])
