@@ -19,6 +19,9 @@ head -8 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-200
 head -14 gpurun_out/${TAG}_bench_pmc_fetch.txt
 # keep the raw kernel trace small enough to merge back: first shot group only
 rm -rf gpurun_out/prof_$TAG   # raw traces and counter CSVs (tens of MB: gpurun merges at most 64 MiB back); the summaries above are what is kept
+# the same bench line with the two-launch backward step (option bwd_fuse=2): what the persistent loop is compared with
+( timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-call32 --option bwd_fuse=2 ) > gpurun_out/${TAG}_bench_two_launch.log 2>&1
+tail -1 gpurun_out/${TAG}_bench_two_launch.log | cut -c1-400
 # configs[1] shape, forward only, un-profiled
 ( timeout -k 10 300 python bench.py --mode fwd --nz 500 --nsteps 2000 --steps 3 --warmup 1 --no-cpu-baseline ) > gpurun_out/${TAG}_fwd2000x500_bench.log 2>&1
 tail -1 gpurun_out/${TAG}_fwd2000x500_bench.log | cut -c1-400

@@ -19,7 +19,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         cnt[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name in sorted(dur, key=lambda n: -sum(dur[n])):
     d = dur[name]
-    if len(d) < 5:
+    if len(d) < 5 and sum(d) < 1000.0:      # (a few long launches -- the persistent loop -- are kept)
         continue
     print("%-62s calls %5d  avg %8.2f us (profiled)" % (name, len(d), sum(d) / len(d)))
     for c in sorted(cnt[name]):
