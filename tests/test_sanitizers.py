@@ -39,3 +39,18 @@ def test_pack_index_and_survey_checks_under_asan_ubsan(tmp_path):
         assert out.stdout.startswith("OK"), out.stdout + out.stderr
         acc = [int(w) for w in out.stdout.split() if w.isdigit()]
         assert min(acc) > 0, out.stdout          # every branch (accepted and refused) was exercised
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_persistent_loop_tiling_under_asan_ubsan(tmp_path):
+    """The host-built tiling of the persistent backward loop (csrc/persist_plan.cpp): every row segment owned once, tiles balanced to
+    +- 1, edge / cross-band flags exactly where a stencil leaves the tile / the band, edge segments first, neighbour lists complete
+    and symmetric -- on the shipped headline plan and on random grids, band counts, workgroup counts and strip widths."""
+    exe = str(tmp_path / "persist_plan_check")
+    src = [os.path.join(ROOT, "tests", "native", "persist_plan_check.cpp"), os.path.join(ROOT, "sep-2023_amd", "csrc", "persist_plan.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-o", exe] + src)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    for seed in (1, 2):
+        out = subprocess.run([exe, str(seed), "300"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
