@@ -1193,7 +1193,7 @@ const OptField kOptFields[] = {
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
-    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
+    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
 };
 }  // namespace
 

@@ -32,6 +32,7 @@ struct KernelOptions {
     int pk_wpc = 2;       //   workgroups (16 waves each) per CU
     int pk_px = 3;        //   strip width of the tiling in row segments (persist_plan.hpp)
     int pk_waves = 16;    //   waves per workgroup
+    int pk_order = 1;     //   1: edge segments first in every phase (the flag goes out early), 0: strip order, the flag goes out at the end of the phase
     int pk_nosync = 0;    //   1: no synchronisation between tiles -- WRONG RESULTS, timing experiments only
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)

@@ -62,7 +62,7 @@ std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w
             ((is_edge || !edge_first) ? edge : inner).push_back(flagged);
         }
         if ((int)nbs.size() > kPlanMaxNb) return "persist plan: a tile has more than " + std::to_string(kPlanMaxNb) + " neighbours";
-        h.n_edge = edge_first ? (int)edge.size() : 0;
+        h.n_edge = (int)edge.size();  // natural order: every segment counts as an edge segment -- the tile publishes a phase when all of it is done
         h.n_seg = (int)(edge.size() + inner.size());
         h.n_nb = (int)nbs.size();
         std::sort(nbs.begin(), nbs.end());

@@ -37,7 +37,8 @@ struct PersistPlan {
 };
 
 // Builds the plan; returns an empty string, or why the grid cannot be tiled this way (e.g. a tile with more than kPlanMaxNb
-// neighbours).  Rows [0, nzc) x segment columns [0, nseg).
+// neighbours).  Rows [0, nzc) x segment columns [0, nseg).  edge_first = false keeps the strip order inside a tile (better cache locality) and
+// lets n_edge = n_seg: such a tile publishes a phase only when it is through with all of it.
 std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true);
 
 }  // namespace sepfwi

@@ -339,7 +339,7 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     if (opt.bwd_fuse != 4) return false;
     if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
     Persist &k = pk_;
-    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
+    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
         if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
         return k.state == 1;
     }
@@ -355,7 +355,8 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
         k.why = "grid too small for " + std::to_string(k.nwg) + " tiles";
         return false;
     }
-    k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan);
+    k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0);
+    k.order = opt.pk_order;
     if (!k.why.empty()) return false;
     // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a in that order; b stays in HBM)
     const size_t lds_cu = 160 * 1024, per_wg = lds_cu / (size_t)opt.pk_wpc - 256;
