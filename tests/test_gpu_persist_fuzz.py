@@ -1,0 +1,51 @@
+"""Seeded random geometries for the persistent backward loop (-m gpu): grid size and aspect, layer width, bottom padding, record
+length, shot positions, strip width of the tiling, LDS mask, imaging interval and the order of a tile's segments are drawn per case; the
+loop must give the two-launch step's misfit, gradients and source gradients BIT FOR BIT (same bodies, same order of operations on
+every array) -- which makes any stale halo read, any missed hand-off between tiles, visible.  No oracle involved: seconds per draw.
+One-off sweeps: SEPFWI_PFUZZ_N=200 (profiles/r05_persist_fuzz.txt)."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+_SEEDS = list(range(int(os.environ.get("SEPFWI_PFUZZ_N", "6"))))
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_persistent_loop_random_geometry_is_bit_identical(tmp_path, hip_ops, seed):
+    rng = np.random.default_rng(4000 + seed)
+    nPml = int(rng.integers(6, 33))
+    # at least 4 x 512 row segments of 64 columns, i.e. every one of the 512 tiles gets a handful; aspect from 1 : 12 to 12 : 1
+    while True:
+        nz, nx = int(rng.integers(40, 900)), int(rng.integers(100, 2400))
+        nPad = int(rng.integers(0, 9))
+        segs = (nz + 2 * nPml) * ((nx + 2 * nPml + 63) // 64)
+        if 2200 <= segs <= 14000:
+            break
+    nSteps = int(rng.integers(150, 420))
+    nshots = int(rng.integers(1, 3))
+    rec_z = int(rng.integers(2, max(3, min(nz - 3, 60))))
+    pb = P.make_problem(str(tmp_path), nz=nz, nx=nx, nPml=nPml, nPad=nPad, nSteps=nSteps, nshots=nshots, hetero=True, seed=seed,
+                        src_z=int(rng.integers(1, 5)), rec_z=rec_z, f0=float(rng.uniform(10.0, 30.0)))
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"], to_store=True)
+    lam, mu, den = pb["lame_init"]
+    lam = (lam * 1.05).contiguous()
+    common = dict(batch=0, img_every=int(rng.choice([1, 1, 1, 2, 3])), early=int(rng.choice([0, 0, 3])))
+    loop = dict(pk_px=int(rng.integers(1, 9)), pk_lmask=int(rng.choice([16, 16, 15, 7, 3, 1, 0])), pk_order=int(rng.integers(0, 2)),
+                pk_wpc=int(rng.choice([2, 2, 2, 1])))
+    with P.kernel_options(bwd_fuse=2, **common):
+        ref = [t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])]
+    with P.kernel_options(bwd_fuse=4, **common, **loop):
+        got = [t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])]
+        steps = hip_ops.stats(pb["para_fname"], 0)["persist_steps"]
+    hip_ops.release()      # (a sweep of thousands of draws would otherwise keep every draw's session and its arrays)
+    desc = dict(seed=seed, nz=nz, nx=nx, nPml=nPml, nPad=nPad, nSteps=nSteps, nshots=nshots, **common, **loop)
+    assert steps == nshots * (nSteps - 1), desc          # the loop really ran
+    for name, a, b in zip(("misfit", "gLambda", "gMu", "gDen", "gStf"), got, ref):
+        assert np.array_equal(a, b), (desc, name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    assert np.isfinite(ref[0]).all() and np.abs(ref[4]).max() > 0, desc      # (the source gradient is alive from the first backward steps on)
