@@ -805,6 +805,7 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
         edge_done = 0;
         abort_flag = 0;
         unsigned int verdict = kPersistGo;
+        if (a.nosync && blockIdx.x == 0) atomicExch(a.band_xcc + 9, kPersistGo);  // (the host reads the decision word)
         if (!a.nosync) {
             unsigned int *arrived = a.band_xcc + 8, *decision = a.band_xcc + 9;
             const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID, 4 bits
