@@ -422,7 +422,8 @@ def main():
                 "config": {"workload": ("configs[2]" if args.mode == "fwdadj" else "configs[1]") + " shape: %dx%d model (padded %dx%d), %d time steps, %d DAS channels, "
                                        "%d shot(s) per GPU per step, %s" % (args.nx, args.nz, pb["nx_pad"], pb["nz_pad"], args.nsteps,
                                                                         pb["nrec"], spr, "forward + boundary-saving adjoint gradient" if args.mode == "fwdadj" else "forward only"),
-                           "cell_updates_per_shot": updates_per_shot, "shots_per_gpu_per_step": spr, "parallelism": "shots x%d" % world},
+                           "cell_updates_per_shot": updates_per_shot, "shots_per_gpu_per_step": spr, "parallelism": "shots x%d" % world,
+                           **({"options": list(args.option)} if args.option else {})},   # a run with non-default library options says so
                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_ratio": traffic_ratio, "kernel": kern,
                              "avg_us": round(per_step_us, 2),

@@ -87,7 +87,11 @@ def main():
     ap.add_argument("--files", action="store_true", help="observed data through Shot_*.bin files as the reference does (default: straight into the HBM store)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend under torchrun (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0: rehearsal of the N-rank run on a one-GPU box (with --backend gloo)")
+    ap.add_argument("--quiet-skip", action="store_true", help="library option quiet_skip: leave out updates whose every input is exactly +0 (same bits, less time)")
     a = ap.parse_args()
+    if a.quiet_skip:
+        from sepfwi import _native
+        _native.check(_native.lib().sepfwi_set_option(b"quiet_skip", 1))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)

@@ -37,11 +37,18 @@ struct Grid {
     int rho_fly;  // 1: buoyancy averages recomputed from the density in the velocity-type kernels
     int amu_fly;  // 1: the 4-point harmonic mean of mu recomputed from mu in the stress-type kernels
     int nb, shot_fastest;  // batched launches: shots per grid and the order of (tile, shot) in the block index
+    int nblk;     // blocks of the launch in the logical numbering (my_cell)
+    int qzw, qn;  // quiet-segment bit maps (option quiet_skip, Fields::q): 32-bit words per segment column, words per map
 };
 
 // Five wavefields (or their adjoint twins), each nzc*pitch floats.
 struct Fields {
     float *vz, *vx, *szz, *sxx, *sxz;
+    // Option quiet_skip (null: off): two bit maps of Grid::qn words each, one bit per ROW SEGMENT (64 columns of one row) -- set once
+    // the velocity-type arrays (vz, vx and the C-PML memories written with them) resp. the stress-type arrays of the segment may hold
+    // a non-zero value.  A segment whose own bit and the bits within reach of the stencil are all clear is left as it is: every
+    // value the update would read is +0, and it would store +0 again.  Layout: column xs + 1 of Grid::qzw words, bit z + 2.
+    unsigned int *q = nullptr;
 };
 
 // Eight C-PML memory variables.  Forward run: psi of the forward fields; backward run: reused as
@@ -102,6 +109,7 @@ struct ShotDev {
     int lr_z, lr_x0, lr_n;  // horizontal line of channels (lr_n == 0: separate k_record / k_inject launches)
     int comps, nrec;
     float src_rxz;
+    unsigned int *quiet;  // null, or the shot's four quiet-segment maps: forward velocity, forward stress, adjoint velocity, adjoint stress
 };
 
 constexpr unsigned int kPersistGo = 1, kPersistAbortResidency = 2, kPersistAbortPlacement = 3;  // start rendezvous of k_bwd_persist

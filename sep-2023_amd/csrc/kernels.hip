@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -55,9 +56,9 @@ struct Cell {
 // (all tiles of shot 0, then shot 1, ...) or, shot_fastest, tile-major: the nb shots of one tile are dispatched back to
 // back on one XCD, so the media coefficients of the tile (the same for every shot) are fetched from the fabric once
 // and hit that XCD's L2 for the other shots.
-__device__ __forceinline__ Cell my_cell(const Grid &g, int *shot = nullptr) {
+__device__ __forceinline__ Cell my_cell(const Grid &g, int *shot = nullptr, int block = -1 /* default: blockIdx.x */) {
     Cell c;
-    int t = blockIdx.x;
+    int t = block < 0 ? (int)blockIdx.x : block;
     const int ntile = g.gx * g.gy;
     const int nb = shot ? g.nb : 1;
     if (g.xcd_remap) {
@@ -152,13 +153,17 @@ struct MemAgent {
 // ---------------------------------------------------------------------------------------------
 // stress update
 // ---------------------------------------------------------------------------------------------
+// Returns whether this lane stored a non-zero value.  quiet (wave-uniform, option quiet_skip): every value the update would read
+// is +0 -- nothing to do but the boundary save and the receiver samples; no_img: the adjoint stresses of the segment are all +0, the
+// imaging condition would add +-0.
 template <bool FWD, bool SAVE, class ACC, class MEM = MemPlain>
-__device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
+__device__ __forceinline__ bool stress_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                             const PmlCoef &pc, float *__restrict__ frame_t,  // this step's 5*frame_len block
                                             int z_src, int x_src, float src_amp,              // scale*stf[it]*dt
-                                            const Fields &adj, const ACC &acc, const LineRec &lr) {
+                                            const Fields &adj, const ACC &acc, const LineRec &lr, bool quiet = false,
+                                            bool no_img = false) {
     const int z = c.z, x = c.x, P = g.pitch;
-    if (z >= g.nzc || x >= g.nx) return;
+    if (z >= g.nzc || x >= g.nx) return false;
     const size_t i = c.i;
 
     if constexpr (FWD) {
@@ -174,7 +179,18 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
                 frame_t[4 * L + s] = f.vx[i];
             }
         }
-        if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_stress.cu:52
+        if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return false;  // el_stress.cu:52
+        if (quiet) {
+            if (lr.n && z == lr.z) {
+                const int r = x - lr.x0;
+                if (r >= 0 && r < lr.n) {
+                    if (lr.d_vx) lr.d_vx[r] = 0.0f;
+                    if (lr.d_vz) lr.d_vz[r] = 0.0f;
+                    if (lr.d_ett) lr.d_ett[r] = 0.0f;
+                }
+            }
+            return false;
+        }
 
         // every unconditional load of the cell is issued here, before the first store: a store makes the compiler
         // keep all later (may-alias) loads behind it, i.e. one more dependent memory round trip per wave
@@ -196,6 +212,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             }
         }
 
+        bool nz = false;
         if (in_pml_z(g, z)) {  // wave-uniform branch
             float p = pc.b_z[z] * m.dvz_dz[i] + pc.a_z[z] * dvz_dz;
             m.dvz_dz[i] = p;
@@ -203,6 +220,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             float q = pc.b_zh[z] * m.dvx_dz[i] + pc.a_zh[z] * dvx_dz;
             m.dvx_dz[i] = q;
             dvx_dz = dvx_dz * pc.rK_zh[z] + q;
+            nz = (p != 0.0f) | (q != 0.0f);
         }
         if (x < g.nPml || x > g.nx - g.nPml - 1) {  // el_stress.cu:61,77
             float p = pc.b_x[x] * m.dvx_dx[i] + pc.a_x[x] * dvx_dx;
@@ -211,6 +229,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             float q = pc.b_xh[x] * m.dvz_dx[i] + pc.a_xh[x] * dvz_dx;
             m.dvz_dx[i] = q;
             dvz_dx = dvz_dx * pc.rK_xh[x] + q;
+            nz |= (p != 0.0f) | (q != 0.0f);
         }
         const float l2m = lam + 2.0f * mu;
         float szz = szz0 + (l2m * dvz_dz + lam * dvx_dx) * g.dt;
@@ -219,14 +238,17 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             szz += src_amp;
             sxx += src_amp;
         }
+        const float sxz = sxz0 + amu * (dvx_dz + dvz_dx) * g.dt;
         f.szz[i] = szz;
         f.sxx[i] = sxx;
-        f.sxz[i] = sxz0 + amu * (dvx_dz + dvz_dx) * g.dt;
+        f.sxz[i] = sxz;
+        return nz | (szz != 0.0f) | (sxx != 0.0f) | (sxz != 0.0f);
     } else {
         // ---- reverse-time reconstruction + lambda/mu imaging ----
+        if (quiet) return false;  // (a segment that never held a value: its saved frames are zeros as well)
         const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
         const int s = frame_slot(g, z, x);
-        if (!interior && s < 0) return;
+        if (!interior && s < 0) return false;
         float szz = 0.f, sxx = 0.f, sxz = 0.f;
         if (interior) {
             szz = MEM::ld(&f.szz[i]);
@@ -241,7 +263,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
             const float dvx_dz = dplus(MEM::ld(&f.vx[i - P]), MEM::ld(&f.vx[i]), MEM::ld(&f.vx[i + P]), MEM::ld(&f.vx[i + 2 * P]), g.rdz);
             const float dvz_dx = dplus(MEM::ld(&f.vz[i - 1]), MEM::ld(&f.vz[i]), MEM::ld(&f.vz[i + 1]), MEM::ld(&f.vz[i + 2]), g.rdx);
             const float lam = md.lam[i], mu = md.mu[i], amu = ave_mu_at(g, md, i, mu);
-            const bool img = g.dt_img != 0.0f;  // launch-uniform: option img_every images every k-th step only
+            const bool img = g.dt_img != 0.0f && !no_img;  // launch-uniform: option img_every images every k-th step only
             float za = 0.f, xa = 0.f, sa = 0.f, g_lam = 0.f, g_mu = 0.f, g_xz = 0.f;
             if (img) {
                 za = MEM::ld(&adj.szz[i]); xa = MEM::ld(&adj.sxx[i]); sa = MEM::ld(&adj.sxz[i]);
@@ -267,6 +289,7 @@ __device__ __forceinline__ void stress_body(const Grid &g, const Cell &c, const 
         MEM::st(&f.szz[i], szz);
         MEM::st(&f.sxx[i], sxx);
         MEM::st(&f.sxz[i], sxz);
+        return (szz != 0.0f) | (sxx != 0.0f) | (sxz != 0.0f);
     }
 }
 
@@ -290,16 +313,17 @@ __device__ __forceinline__ void buoyancies(const Grid &g, const Media &md, size_
 }
 
 template <bool FWD, class ACC, class MEM = MemPlain>
-__device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
+__device__ __forceinline__ bool velocity_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md,
                                               const PmlCoef &pc, const float *__restrict__ frame_t, int z_src, int x_src,
                                               float src_rxz, float *__restrict__ stf_grad_it, const Fields &adj,
-                                              const ACC &acc) {
+                                              const ACC &acc, bool quiet = false, bool no_img = false) {
     const int z = c.z, x = c.x, P = g.pitch;
-    if (z >= g.nzc || x >= g.nx) return;
+    if (z >= g.nzc || x >= g.nx) return false;
     const size_t i = c.i;
 
     if constexpr (FWD) {
-        if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return;  // el_velocity.cu:47
+        if (z < 2 || z > g.nzc - 3 || x < 2 || x > g.nx - 3) return false;  // el_velocity.cu:47
+        if (quiet) return false;
         float dszz_dz = dplus(f.szz[i - P], f.szz[i], f.szz[i + P], f.szz[i + 2 * P], g.rdz);
         float dsxz_dx = dminus(f.sxz[i - 2], f.sxz[i - 1], f.sxz[i], f.sxz[i + 1], g.rdx);
         float dsxz_dz = dminus(f.sxz[i - 2 * P], f.sxz[i - P], f.sxz[i], f.sxz[i + P], g.rdz);
@@ -307,6 +331,7 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
         const float vz0 = f.vz[i], vx0 = f.vx[i];  // all loads before the first store
         float ba, bb;
         buoyancies(g, md, i, ba, bb);
+        bool nz = false;
         if (in_pml_z(g, z)) {
             float p = pc.b_zh[z] * m.dszz_dz[i] + pc.a_zh[z] * dszz_dz;
             m.dszz_dz[i] = p;
@@ -314,6 +339,7 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             float q = pc.b_z[z] * m.dsxz_dz[i] + pc.a_z[z] * dsxz_dz;
             m.dsxz_dz[i] = q;
             dsxz_dz = dsxz_dz * pc.rK_z[z] + q;
+            nz = (p != 0.0f) | (q != 0.0f);
         }
         if (x < g.nPml || x > g.nx - g.nPml) {  // el_velocity.cu:56,71 (one column narrower on the right)
             float p = pc.b_x[x] * m.dsxz_dx[i] + pc.a_x[x] * dsxz_dx;
@@ -322,22 +348,27 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
             float q = pc.b_xh[x] * m.dsxx_dx[i] + pc.a_xh[x] * dsxx_dx;
             m.dsxx_dx[i] = q;
             dsxx_dx = dsxx_dx * pc.rK_xh[x] + q;
+            nz |= (p != 0.0f) | (q != 0.0f);
         }
-        f.vz[i] = vz0 + (dszz_dz + dsxz_dx) * ba * g.dt;
-        f.vx[i] = vx0 + (dsxz_dz + dsxx_dx) * bb * g.dt;
+        const float vz = vz0 + (dszz_dz + dsxz_dx) * ba * g.dt;
+        const float vx = vx0 + (dsxz_dz + dsxx_dx) * bb * g.dt;
+        f.vz[i] = vz;
+        f.vx[i] = vx;
+        return nz | (vz != 0.0f) | (vx != 0.0f);
     } else {
         // source_grad uses the adjoint stresses as they stand at the start of the step (libCUFD.cu:547)
         if (z == z_src && x == x_src) *stf_grad_it = -(MEM::ld(&adj.szz[i]) + src_rxz * MEM::ld(&adj.sxx[i])) * g.dt;
+        if (quiet) return false;
         const bool interior = (z >= g.nPml && z <= g.zmax && x >= g.nPml && x <= g.xmax);
         const int s = frame_slot(g, z, x);
-        if (!interior && s < 0) return;
+        if (!interior && s < 0) return false;
         float vz = 0.f, vx = 0.f;
         if (interior) {
             const float dszz_dz = dplus(MEM::ld(&f.szz[i - P]), MEM::ld(&f.szz[i]), MEM::ld(&f.szz[i + P]), MEM::ld(&f.szz[i + 2 * P]), g.rdz);
             const float dsxz_dx = dminus(MEM::ld(&f.sxz[i - 2]), MEM::ld(&f.sxz[i - 1]), MEM::ld(&f.sxz[i]), MEM::ld(&f.sxz[i + 1]), g.rdx);
             const float dsxz_dz = dminus(MEM::ld(&f.sxz[i - 2 * P]), MEM::ld(&f.sxz[i - P]), MEM::ld(&f.sxz[i]), MEM::ld(&f.sxz[i + P]), g.rdz);
             const float dsxx_dx = dplus(MEM::ld(&f.sxx[i - 1]), MEM::ld(&f.sxx[i]), MEM::ld(&f.sxx[i + 1]), MEM::ld(&f.sxx[i + 2]), g.rdx);
-            const bool img = g.dt_img != 0.0f;  // launch-uniform
+            const bool img = g.dt_img != 0.0f && !no_img;  // launch-uniform
             float g_a = 0.f, g_b = 0.f, avz = 0.f, avx = 0.f;
             if (img) {
                 g_a = acc.template ld<ACC_A>(i); g_b = acc.template ld<ACC_B>(i); avz = MEM::ld(&adj.vz[i]); avx = MEM::ld(&adj.vx[i]);
@@ -359,6 +390,7 @@ __device__ __forceinline__ void velocity_body(const Grid &g, const Cell &c, cons
         }
         MEM::st(&f.vz[i], vz);
         MEM::st(&f.vx[i], vx);
+        return (vz != 0.0f) | (vx != 0.0f);
     }
 }
 
@@ -413,9 +445,9 @@ __device__ __forceinline__ VelAdjIn velocity_adj_load(const Grid &g, const Cell 
     return q;
 }
 template <class MEM = MemPlain>
-__device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
+__device__ __forceinline__ bool velocity_adj_apply(const VelAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
                                                    const PmlMem &m, const Media &md, const PmlCoef &pc, const LineRec &lr) {
-    if (!q.on) return;
+    if (!q.on) return false;
     const int z = c.z, x = c.x, P = g.pitch;
     const size_t i = c.i;
     const bool pz = in_pml_z(g, z);
@@ -443,6 +475,7 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
     }
     const float vx = q.vx + upd;
     const float vz = q.vz + upz;
+    bool nz = vz != 0.0f;
     {
         // res_injection_exx (utilities.cu:605-615) for line receivers, applied by the thread that owns the cell:
         // vx_adj(z,x) += r[x]; vx_adj(z,x) -= r[x+1]   (after this kernel's update, libCUFD.cu:585-610)
@@ -453,25 +486,32 @@ __device__ __forceinline__ void velocity_adj_apply(const VelAdjIn &q, const Grid
             if (r + 1 >= 0 && r + 1 < lr.n) vs -= lr.res[r + 1];
         }
         MEM::st(&f.vx[i], vs);
+        nz |= (vs != 0.0f) | (vx != 0.0f);
     }
     MEM::st(&f.vz[i], vz);
     if (px || pz) {  // the buoyancies are only needed inside the layers: keep their loads out of the interior
         const float bb = md.byc_b[i], ba = md.byc_a[i];
         if (px) {
-            MEM::st(&m.dsxx_dx[i], pc.b_xh[x] * MEM::ld(&m.dsxx_dx[i]) + bb * vx * g.dt);
-            MEM::st(&m.dsxz_dx[i], pc.b_x[x] * MEM::ld(&m.dsxz_dx[i]) + ba * vz * g.dt);
+            const float p = pc.b_xh[x] * MEM::ld(&m.dsxx_dx[i]) + bb * vx * g.dt, q2 = pc.b_x[x] * MEM::ld(&m.dsxz_dx[i]) + ba * vz * g.dt;
+            MEM::st(&m.dsxx_dx[i], p);
+            MEM::st(&m.dsxz_dx[i], q2);
+            nz |= (p != 0.0f) | (q2 != 0.0f);
         }
         if (pz) {
-            MEM::st(&m.dsxz_dz[i], pc.b_z[z] * MEM::ld(&m.dsxz_dz[i]) + bb * vx * g.dt);
-            MEM::st(&m.dszz_dz[i], pc.b_zh[z] * MEM::ld(&m.dszz_dz[i]) + ba * vz * g.dt);
+            const float p = pc.b_z[z] * MEM::ld(&m.dsxz_dz[i]) + bb * vx * g.dt, q2 = pc.b_zh[z] * MEM::ld(&m.dszz_dz[i]) + ba * vz * g.dt;
+            MEM::st(&m.dsxz_dz[i], p);
+            MEM::st(&m.dszz_dz[i], q2);
+            nz |= (p != 0.0f) | (q2 != 0.0f);
         }
     }
+    return nz;
 }
 template <class MEM = MemPlain>
-__device__ __forceinline__ void velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
-                                                  const Media &md, const PmlCoef &pc, const LineRec &lr) {
+__device__ __forceinline__ bool velocity_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
+                                                  const Media &md, const PmlCoef &pc, const LineRec &lr, bool quiet = false) {
+    if (quiet) return false;  // (wave-uniform: every adjoint value within reach is +0 and no channel of the line lies in the segment)
     const VelAdjIn q = velocity_adj_load<MEM>(g, c, f, md, pc);
-    velocity_adj_apply<MEM>(q, g, c, f, m, md, pc, lr);
+    return velocity_adj_apply<MEM>(q, g, c, f, m, md, pc, lr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,9 +544,9 @@ __device__ __forceinline__ StressAdjIn stress_adj_load(const Grid &g, const Cell
     return q;
 }
 template <class MEM = MemPlain>
-__device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
+__device__ __forceinline__ bool stress_adj_apply(const StressAdjIn &q, const Grid &g, const Cell &c, const Fields &f,
                                                  const PmlMem &m, const Media &md, const PmlCoef &pc) {
-    if (!q.on) return;
+    if (!q.on) return false;
     const int z = c.z, x = c.x, P = g.pitch;
     const size_t i = c.i;
     const bool pz = in_pml_z(g, z);
@@ -538,40 +578,160 @@ __device__ __forceinline__ void stress_adj_apply(const StressAdjIn &q, const Gri
     MEM::st(&f.sxz[i], sxz);
     MEM::st(&f.sxx[i], sxx);
     MEM::st(&f.szz[i], szz);
+    bool nz = (sxz != 0.0f) | (sxx != 0.0f) | (szz != 0.0f);
     if (wx || wz) {  // lambda, mu, ave_mu only feed the memory variables, which only exist near the layers
         const float amu = md.ave_mu[i];
         const float lam = md.lam[i], mu = md.mu[i];
         const float l2m = lam + 2.0f * mu;
         if (wx) {
-            MEM::st(&m.dvz_dx[i], pc.b_xh[x] * MEM::ld(&m.dvz_dx[i]) + sxz * amu * g.dt);
-            MEM::st(&m.dvx_dx[i], pc.b_x[x] * MEM::ld(&m.dvx_dx[i]) + lam * szz * g.dt + l2m * sxx * g.dt);
+            const float p = pc.b_xh[x] * MEM::ld(&m.dvz_dx[i]) + sxz * amu * g.dt, q2 = pc.b_x[x] * MEM::ld(&m.dvx_dx[i]) + lam * szz * g.dt + l2m * sxx * g.dt;
+            MEM::st(&m.dvz_dx[i], p);
+            MEM::st(&m.dvx_dx[i], q2);
+            nz |= (p != 0.0f) | (q2 != 0.0f);
         }
         if (wz) {
-            MEM::st(&m.dvx_dz[i], pc.b_zh[z] * MEM::ld(&m.dvx_dz[i]) + sxz * amu * g.dt);
-            MEM::st(&m.dvz_dz[i], pc.b_z[z] * MEM::ld(&m.dvz_dz[i]) + l2m * szz * g.dt + lam * sxx * g.dt);
+            const float p = pc.b_zh[z] * MEM::ld(&m.dvx_dz[i]) + sxz * amu * g.dt, q2 = pc.b_z[z] * MEM::ld(&m.dvz_dz[i]) + l2m * szz * g.dt + lam * sxx * g.dt;
+            MEM::st(&m.dvx_dz[i], p);
+            MEM::st(&m.dvz_dz[i], q2);
+            nz |= (p != 0.0f) | (q2 != 0.0f);
         }
     }
+    return nz;
 }
 template <class MEM = MemPlain>
-__device__ __forceinline__ void stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
-                                                const Media &md, const PmlCoef &pc) {
+__device__ __forceinline__ bool stress_adj_body(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m,
+                                                const Media &md, const PmlCoef &pc, bool quiet = false) {
+    if (quiet) return false;
     const StressAdjIn q = stress_adj_load<MEM>(g, c, f, md, pc);
-    stress_adj_apply<MEM>(q, g, c, f, m, md, pc);
+    return stress_adj_apply<MEM>(q, g, c, f, m, md, pc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quiet segments (option quiet_skip; Fields::q, fwi_types.hpp).  A wavefield is exactly +0 ahead of its numerical front -- on the
+// headline model the forward field fills a fifth of the grid on average over a shot, the adjoint field grows downwards from the
+// channels -- and an update whose every input is +0 stores +0 again: the bodies skip it, bit for bit the same arrays.  One bit per
+// row segment and field group says "may hold a non-zero value"; it is set (never cleared) by the wave that stores one, and read by
+// the waves of LATER launches only (each update reads the other group's map and sets its own group's bits; its own bit is the
+// segment's own).  All arguments are wave-uniform.
+// ---------------------------------------------------------------------------------------------
+typedef const unsigned int __attribute__((address_space(4))) *qmap_t;  // read through the scalar cache: the map an update READS is not written
+                                                                        // in the same launch (only the other group's is), its own bit only by itself
+__device__ __forceinline__ unsigned int q_bit(const unsigned int *q, const Grid &g, int z, int xs) {
+    const int r = z + 2;
+    return (((qmap_t)q)[(size_t)(xs + 1) * (size_t)g.qzw + (size_t)(r >> 5)] >> (r & 31)) & 1u;
+}
+// rows z - 2 ... z + 2 of segment column xs, and row z of the two neighbouring columns: everything a stencil centred in (z, xs) reads
+__device__ __forceinline__ unsigned int q_reach(const unsigned int *q, const Grid &g, int z, int xs) {
+    const qmap_t col = (qmap_t)q + (size_t)(xs + 1) * (size_t)g.qzw + (size_t)(z >> 5);  // bit of row z - 2 is z
+    const unsigned long long v = (unsigned long long)col[0] | ((unsigned long long)col[1] << 32);
+    return ((unsigned int)(v >> (z & 31)) & 0x1fu) | q_bit(q, g, z, xs - 1) | q_bit(q, g, z, xs + 1);
+}
+__device__ __forceinline__ void q_mark(unsigned int *q, const Grid &g, int z, int xs, bool nz, bool already) {
+    if (!already && __ballot(nz) != 0ull && (threadIdx.x & (BX - 1)) == 0) {
+        const int r = z + 2;
+        atomicOr(&q[(size_t)(xs + 1) * (size_t)g.qzw + (size_t)(r >> 5)], 1u << (r & 31));
+    }
+}
+__device__ __forceinline__ int seg_of(const Cell &c) { return __builtin_amdgcn_readfirstlane(c.x) >> 6; }
+
+// The four updates with their maps.  (ONE instance of each body, whatever the option says: two would double the kernels' code.)
+template <bool Q, bool FWD, bool SAVE, class ACC>
+__device__ __forceinline__ void stress_update(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md, const PmlCoef &pc,
+                                              float *__restrict__ frame_t, int z_src, int x_src, float src_amp, const Fields &adj,
+                                              const ACC &acc, const LineRec &lr) {
+    if constexpr (!Q) {
+        stress_body<FWD, SAVE>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr);
+        return;
+    }
+    const int z = c.z;
+    const bool on = f.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    bool own = true, quiet = false, no_img = false;
+    int xs = 0;
+    if (on) {
+        xs = seg_of(c);
+        own = q_bit(f.q + g.qn, g, z, xs) != 0;
+        const bool src = z == z_src && (x_src >> 6) == xs && src_amp != 0.0f;
+        quiet = !(own || src || q_reach(f.q, g, z, xs) != 0);
+        no_img = !FWD && adj.q && q_bit(adj.q + g.qn, g, z, xs) == 0;
+    }
+    const bool nz = stress_body<FWD, SAVE>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr, quiet, no_img);
+    if (on) q_mark(f.q + g.qn, g, z, xs, nz, own);
+}
+template <bool Q, bool FWD, class ACC>
+__device__ __forceinline__ void velocity_update(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md, const PmlCoef &pc,
+                                                const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
+                                                float *__restrict__ stf_grad_it, const Fields &adj, const ACC &acc) {
+    if constexpr (!Q) {
+        velocity_body<FWD>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
+        return;
+    }
+    const int z = c.z;
+    const bool on = f.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    bool own = true, quiet = false, no_img = false;
+    int xs = 0;
+    if (on) {
+        xs = seg_of(c);
+        own = q_bit(f.q, g, z, xs) != 0;
+        quiet = !(own || q_reach(f.q + g.qn, g, z, xs) != 0);
+        no_img = !FWD && adj.q && q_bit(adj.q, g, z, xs) == 0;
+    }
+    const bool nz = velocity_body<FWD>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc, quiet, no_img);
+    if (on) q_mark(f.q, g, z, xs, nz, own);
+}
+template <bool Q>
+__device__ __forceinline__ void velocity_adj_update(const Grid &g, const Cell &c, const Fields &adj, const PmlMem &m, const Media &md,
+                                                    const PmlCoef &pc, const LineRec &lr) {
+    if constexpr (!Q) {
+        velocity_adj_body(g, c, adj, m, md, pc, lr);
+        return;
+    }
+    const int z = c.z;
+    const bool on = adj.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    bool own = true, quiet = false;
+    int xs = 0;
+    if (on) {
+        xs = seg_of(c);
+        own = q_bit(adj.q, g, z, xs) != 0;
+        // the residual of the step is injected into cells lr.x0 - 1 ... lr.x0 + lr.n - 1 of row lr.z
+        const bool rec = lr.n && z == lr.z && xs * BX + BX - 1 >= lr.x0 - 1 && xs * BX <= lr.x0 + lr.n - 1;
+        quiet = !(own || rec || q_reach(adj.q + g.qn, g, z, xs) != 0);
+    }
+    const bool nz = velocity_adj_body(g, c, adj, m, md, pc, lr, quiet);
+    if (on) q_mark(adj.q, g, z, xs, nz, own);
+}
+template <bool Q>
+__device__ __forceinline__ void stress_adj_update(const Grid &g, const Cell &c, const Fields &adj, const PmlMem &m, const Media &md,
+                                                  const PmlCoef &pc) {
+    if constexpr (!Q) {
+        stress_adj_body(g, c, adj, m, md, pc);
+        return;
+    }
+    const int z = c.z;
+    const bool on = adj.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    bool own = true, quiet = false;
+    int xs = 0;
+    if (on) {
+        xs = seg_of(c);
+        own = q_bit(adj.q + g.qn, g, z, xs) != 0;
+        quiet = !(own || q_reach(adj.q, g, z, xs) != 0);
+    }
+    const bool nz = stress_adj_body(g, c, adj, m, md, pc, quiet);
+    if (on) q_mark(adj.q + g.qn, g, z, xs, nz, own);
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernels: one body each (the reference's launch structure) ...
 // ---------------------------------------------------------------------------------------------
-template <bool FWD, bool SAVE>
+template <bool FWD, bool SAVE, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
                                                  int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc, LineRec lr) {
-    stress_body<FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
+    stress_update<Q, FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
 }
-template <bool FWD>
+template <bool FWD, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
                                                    const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
                                                    float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
-    velocity_body<FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
+    velocity_update<Q, FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     velocity_adj_body(g, my_cell(g), f, m, md, pc, LineRec{});
@@ -605,6 +765,7 @@ struct BwdArgs {
     float *acc;          // lam, mu, xz, a, b              (stride n)
     const float *cz;     // z profiles a, b, 1/K, a_half, b_half, 1/K_half (stride nzc), then the six x profiles (stride nx)
     size_t n;
+    unsigned int *qf, *qa;  // quiet-segment maps of the forward / adjoint fields (Fields::q), or null
 };
 __device__ __forceinline__ Fields fields_of(float *b, size_t n) { return Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n}; }
 __device__ __forceinline__ PmlMem mem_of(float *b, size_t n) {
@@ -617,14 +778,21 @@ __device__ __forceinline__ PmlCoef coef_of(const float *cz, const float *cx, int
                    cx, cx + nx,  cx + 2 * nx,  cx + 3 * nx,  cx + 4 * nx,  cx + 5 * nx};
 }
 
-template <bool EARLY>
+template <bool EARLY, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *__restrict__ frame_t) {
-    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    f.q = b.qf;
+    adj.q = b.qa;
     const PmlMem m = mem_of(b.mem, b.n);
     const Media md = media_of(b.media, b.n);
     const ImgAcc acc = acc_of(b.acc, b.n);
     const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
+    if constexpr (Q) {
+        velocity_update<Q, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
+        stress_adj_update<Q>(g, c, adj, m, md, pc);
+        return;
+    }
     if constexpr (EARLY) {  // adjoint-stress loads in flight together with the reverse-velocity loads
         const StressAdjIn q = stress_adj_load(g, c, adj, md, pc);
         velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
@@ -634,13 +802,15 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
         stress_adj_body(g, c, adj, m, md, pc);
     }
 }
-template <bool EARLY>
+template <bool EARLY, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__restrict__ frame_t, int zx_src /* z<<16 | x */,
                                                 float src_amp, float src_rxz, float *__restrict__ stf_grad_it,
                                                 int lr_zx /* z<<16 | x0 */, int lr_n, const float *__restrict__ lr_res) {
     const int z_src = zx_src >> 16, x_src = zx_src & 0xffff;
     const LineRec lr{lr_zx >> 16, lr_zx & 0xffff, lr_n, nullptr, nullptr, nullptr, lr_res};
-    const Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    Fields f = fields_of(b.fields, b.n), adj = fields_of(b.adj, b.n);
+    f.q = b.qf;
+    adj.q = b.qa;
     const PmlMem m = mem_of(b.mem, b.n);
     const Media md = media_of(b.media, b.n);
     const ImgAcc acc = acc_of(b.acc, b.n);
@@ -648,6 +818,11 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
     const Cell c = my_cell(g);
     // source_grad (utilities.cu:719-730): adjoint stresses after the adjoint stress update of the previous step
     if (c.z == z_src && c.x == x_src) *stf_grad_it = -(adj.szz[c.i] + src_rxz * adj.sxx[c.i]) * g.dt;
+    if constexpr (Q) {
+        stress_update<Q, false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, LineRec{});
+        velocity_adj_update<Q>(g, c, adj, m, md, pc, lr);
+        return;
+    }
     if constexpr (EARLY) {  // adjoint-velocity loads in flight together with the reverse-stress loads
         const VelAdjIn q = velocity_adj_load(g, c, adj, md, pc);
         stress_body<false, false>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, LineRec{});
@@ -664,14 +839,15 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b(Grid g, BwdArgs b, float *__rest
 // 24 launches per shot and time step; the stream form 4; this one 4 / batch), and on the headline grid the three
 // concurrent forward passes become one launch whose blocks pack without stream scheduling.  Same bodies as above.
 // ---------------------------------------------------------------------------------------------
-template <bool SAVE>
+template <bool SAVE, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                            const float *__restrict__ cz, size_t n, size_t data_len, int it,
                                                            float src_scale) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const Fields f = fields_of(s.fields, n);
+    Fields f = fields_of(s.fields, n);
+    f.q = s.quiet;
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
@@ -688,26 +864,30 @@ __global__ __launch_bounds__(MAXT) void k_stress_fwd_batch(Grid g, const ShotDev
         lr.d_vz = (s.comps & 4) ? s.syn + 2 * data_len + c0 : nullptr;
         lr.d_ett = (s.comps & 8) ? s.syn + 3 * data_len + c0 : nullptr;
     }
-    stress_body<true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, AccG{}, lr);
+    stress_update<Q, true, SAVE>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, Fields{}, AccG{}, lr);
 }
+template <bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_velocity_fwd_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                              const float *__restrict__ cz, size_t n) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const Fields f = fields_of(s.fields, n);
+    Fields f = fields_of(s.fields, n);
+    f.q = s.quiet;
     const PmlMem m = mem_of(s.mem, n);
     const Media md = media_of(media, n);
     const PmlCoef pc = coef_of(cz, cz + 6 * g.nzc, g.nzc, g.nx);
-    velocity_body<true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, AccG{});
+    velocity_update<Q, true>(g, c, f, m, md, pc, nullptr, -1, -1, 0.0f, nullptr, Fields{}, AccG{});
 }
-template <bool EARLY>
+template <bool EARLY, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                       const float *__restrict__ cz, size_t n, int it) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    f.q = s.quiet;
+    adj.q = s.quiet ? s.quiet + 2 * (size_t)g.qn : nullptr;
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(media, n);
     const ImgAcc acc = acc_of(s.acc, n);
@@ -718,17 +898,19 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a_batch(Grid g, const ShotDev *__r
         velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
         stress_adj_apply(q, g, c, adj, m, md, pc);
     } else {
-        velocity_body<false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
-        stress_adj_body(g, c, adj, m, md, pc);
+        velocity_update<Q, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
+        stress_adj_update<Q>(g, c, adj, m, md, pc);
     }
 }
-template <bool EARLY>
+template <bool EARLY, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__restrict__ shots, const float *__restrict__ media,
                                                       const float *__restrict__ cz, size_t n, int it, float src_scale) {
     int ish;
     const Cell c = my_cell(g, &ish);
     const ShotDev &s = shots[ish];
-    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    f.q = s.quiet;
+    adj.q = s.quiet ? s.quiet + 2 * (size_t)g.qn : nullptr;
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(media, n);
     const ImgAcc acc = acc_of(s.acc, n);
@@ -742,8 +924,8 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
         stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
         velocity_adj_apply(q, g, c, adj, m, md, pc, lr);
     } else {
-        stress_body<false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
-        velocity_adj_body(g, c, adj, m, md, pc, lr);
+        stress_update<Q, false, false>(g, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, AccG{acc}, LineRec{});
+        velocity_adj_update<Q>(g, c, adj, m, md, pc, lr);
     }
 }
 
@@ -1193,6 +1375,7 @@ const OptField kOptFields[] = {
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
+    {"quiet_skip", &KernelOptions::quiet_skip, 0, 1},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
     {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
 };
@@ -1227,12 +1410,11 @@ static inline Grid tiled(const Grid &g0, const KernelOptions &o, int fly_bit = -
     g.rho_fly = fly_bit < 0 ? 0 : (o.rho_fly >> fly_bit) & 1;
     g.amu_fly = fly_bit < 0 ? 0 : (o.amu_fly >> fly_bit) & 1;
     g.rk_lazy = o.rk_lazy;
+    const int nb = g.gx * g.gy;
+    g.nblk = g.xcd_remap ? ((nb + 7) / 8) * 8 : nb;
     return g;
 }
-static inline dim3 field_grid(const Grid &g) {
-    const int nb = g.gx * g.gy;
-    return dim3(g.xcd_remap ? ((nb + 7) / 8) * 8 : nb);
-}
+static inline dim3 field_grid(const Grid &g) { return dim3(g.nblk); }
 #define BLOCK dim3(BX *g.bz)
 
 void launch_stress_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
@@ -1240,20 +1422,16 @@ void launch_stress_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, F
     const Grid g = tiled(g0, o, 0);
     Fields none{};
     ImgAcc na{};
-    if (frame_t)
-        hipLaunchKernelGGL((k_stress<true, true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
-                           x_src, src_amp, none, na, lr);
-    else
-        hipLaunchKernelGGL((k_stress<true, false>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src,
-                           x_src, src_amp, none, na, lr);
+    auto k = frame_t ? (f.q ? k_stress<true, true, true> : k_stress<true, true, false>) : (f.q ? k_stress<true, false, true> : k_stress<true, false, false>);
+    hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, frame_t, z_src, x_src, src_amp, none, na, lr);
 }
 
 void launch_velocity_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc) {
     const Grid g = tiled(g0, o, 0);
     Fields none{};
     ImgAcc na{};
-    hipLaunchKernelGGL((k_velocity<true>), field_grid(g), BLOCK, 0, st, g, f, m, md, pc, (const float *)nullptr,
-                       -1, -1, 0.0f, (float *)nullptr, none, na);
+    auto k = f.q ? k_velocity<true, true> : k_velocity<true, false>;
+    hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, f, m, md, pc, (const float *)nullptr, -1, -1, 0.0f, (float *)nullptr, none, na);
 }
 
 void launch_velocity_rev(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, Media md, PmlCoef pc,
@@ -1307,8 +1485,8 @@ void launch_bwd_a(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                   const float *frame_t, Fields adj, ImgAcc acc) {
     const Grid g = tiled(g0, o, 1);
     check_bundles(g, f, m, md, pc, adj, acc);
-    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};
-    auto k = (o.early & 1) ? k_bwd_a<true> : k_bwd_a<false>;
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz), f.q, adj.q};
+    auto k = f.q ? k_bwd_a<false, true> : (o.early & 1) ? k_bwd_a<true, false> : k_bwd_a<false, false>;
     hipLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, g, b, frame_t);
 }
 
@@ -1317,8 +1495,8 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                   hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
     check_bundles(g, f, m, md, pc, adj, acc);
-    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz)};
-    auto k = (o.early & 2) ? k_bwd_b<true> : k_bwd_b<false>;
+    const BwdArgs b{f.vz, m.dvz_dz, adj.vz, md.lam, acc.lam, pc.a_z, (size_t)(f.vx - f.vz), f.q, adj.q};
+    auto k = f.q ? k_bwd_b<false, true> : (o.early & 2) ? k_bwd_b<true, false> : k_bwd_b<false, false>;
     if (ev_start)  // timestamps taken by the command processor at kernel begin / end (no launch gap included)
         hipExtLaunchKernelGGL(k, field_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, b, frame_t, (z_src << 16) | x_src, src_amp,
                               src_rxz, stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
@@ -1377,6 +1555,8 @@ static inline Grid tiled_batch(const Grid &g0, const KernelOptions &o, int fly_b
     Grid g = tiled(g0, o, fly_bit);
     g.nb = nb;
     g.shot_fastest = o.batch_order;
+    const int nblk = g.gx * g.gy * g.nb;
+    g.nblk = g.xcd_remap ? ((nblk + 7) / 8) * 8 : nblk;
     return g;
 }
 static void check_shared_bundles(const Grid &g, const Media &md, const PmlCoef &pc) {
@@ -1387,39 +1567,34 @@ static void check_shared_bundles(const Grid &g, const Media &md, const PmlCoef &
                          pc.rK_xh - pc.b_xh == x;
     if (!(media_ok && coef_ok)) throw std::logic_error("batched kernel launch: media or C-PML profiles are not laid out as one bundle");
 }
-static inline dim3 batch_grid(const Grid &g) {
-    const int nblk = g.gx * g.gy * g.nb;
-    return dim3(g.xcd_remap ? ((nblk + 7) / 8) * 8 : nblk);
-}
+static inline dim3 batch_grid(const Grid &g) { return dim3(g.nblk); }
 void launch_stress_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                              PmlCoef pc, size_t n, size_t data_len, int it, float src_scale, bool save) {
     const Grid g = tiled_batch(g0, o, 0, nb);
     check_shared_bundles(g, md, pc);
-    if (save)
-        hipLaunchKernelGGL(k_stress_fwd_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
-    else
-        hipLaunchKernelGGL(k_stress_fwd_batch<false>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
+    const bool q = o.quiet_skip != 0;  // (per shot: ShotDev::quiet)
+    auto k = save ? (q ? k_stress_fwd_batch<true, true> : k_stress_fwd_batch<true, false>) : (q ? k_stress_fwd_batch<false, true> : k_stress_fwd_batch<false, false>);
+    hipLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, data_len, it, src_scale);
 }
 void launch_velocity_fwd_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md,
                                PmlCoef pc, size_t n) {
     const Grid g = tiled_batch(g0, o, 0, nb);
     check_shared_bundles(g, md, pc);
-    hipLaunchKernelGGL(k_velocity_fwd_batch, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
+    auto k = o.quiet_skip ? k_velocity_fwd_batch<true> : k_velocity_fwd_batch<false>;
+    hipLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n);
 }
 void launch_bwd_a_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it) {
     const Grid g = tiled_batch(g0, o, 1, nb);
     check_shared_bundles(g, md, pc);
-    if (o.early & 1)
-        hipLaunchKernelGGL(k_bwd_a_batch<true>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
-    else
-        hipLaunchKernelGGL(k_bwd_a_batch<false>, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
+    auto k = o.quiet_skip ? k_bwd_a_batch<false, true> : (o.early & 1) ? k_bwd_a_batch<true, false> : k_bwd_a_batch<false, false>;
+    hipLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, g, shots, md.lam, pc.a_z, n, it);
 }
 void launch_bwd_b_batch(hipStream_t st, const Grid &g0, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled_batch(g0, o, 1, nb);
     check_shared_bundles(g, md, pc);
-    auto k = (o.early & 2) ? k_bwd_b_batch<true> : k_bwd_b_batch<false>;
+    auto k = o.quiet_skip ? k_bwd_b_batch<false, true> : (o.early & 2) ? k_bwd_b_batch<true, false> : k_bwd_b_batch<false, false>;
     if (ev_start)
         hipExtLaunchKernelGGL(k, batch_grid(g), BLOCK, 0, st, ev_start, ev_stop, 0, g, shots, md.lam, pc.a_z, n, it, src_scale);
     else

@@ -56,6 +56,8 @@ void Session::init_grid() {
     g.nzBnd = g.nzc - 2 * par.nPml + 4;  // Boundary.cu:17-18
     g.nxBnd = par.nx - 2 * par.nPml + 4;
     g.frame_len = 10 * g.nxBnd + 10 * (g.nzBnd - 10);
+    g.qzw = ((g.nzc + 4) >> 5) + 2;          // quiet-segment maps (Fields::q): bits z + 2 of rows -2 ... nzc + 1, one spare word for the 64-bit window
+    g.qn = (g.pitch / 64 + 2) * g.qzw;        // segment columns -1 ... pitch / 64
 
 }
 
@@ -77,6 +79,7 @@ void Session::alloc_arrays() {
     HIP_OK(hipDeviceSynchronize());  // the fill runs on the null stream and does not block the host; a caller's non-blocking stream would not wait for it
     md_ = Media{media_, media_ + n, media_ + 2 * n, media_ + 3 * n, media_ + 4 * n, media_ + 5 * n};
     acc_buf_ = dalloc<float>(5 * n);
+    quiet_pool_ = dalloc<unsigned int>((size_t)kQuietSlots * 4 * (size_t)g.qn);
     acc_ = ImgAcc{acc_buf_, acc_buf_ + n, acc_buf_ + 2 * n, acc_buf_ + 3 * n, acc_buf_ + 4 * n};
     const size_t dense = (size_t)par.nz * (size_t)par.nx;
     in_stage_ = dalloc<float>(3 * dense);
@@ -367,6 +370,8 @@ void Session::stats(sepfwi_stats *out) const {
     out->obs_host_bytes = obs_->host_bytes();
     out->obs_evictions = obs_->evictions();
     out->persist_steps = persist_steps_;
+    out->quiet_active = quiet_active_;
+    out->quiet_total = quiet_total_;
     out->probe_kernel_us = probe_calls_ ? probe_us_ / (double)probe_calls_ : 0.0;
     out->probe_calls = probe_calls_;
     // one forward pass = N_c*(nSteps-1); fwd+adj = 3x (forward, reconstruction, adjoint)

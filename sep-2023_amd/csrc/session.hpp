@@ -72,6 +72,7 @@ class Session {
         bool scratch;
         LineRec line;
         float *state;  // [5 fields | 8 memory variables] of this lane
+        unsigned int *quiet;  // option quiet_skip: the lane's four quiet-segment maps (forward v, forward s, adjoint v, adjoint s), or null
         Fields fld;
         PmlMem mem;
         float *frame, *syn, *res;
@@ -87,6 +88,9 @@ class Session {
     void prepare_buffers(Call &c, const float *stf);
     ShotCtx make_ctx(const Call &c, int is, int lane, hipStream_t lane_st, bool with_obs = true);
     void use_state(ShotCtx &x, float *state) const;
+    static constexpr int kQuietSlots = 4 + 64;  // one per stream lane (kMaxLanes) and batch lane (option batch_f <= 64)
+    unsigned int *quiet_slot(int slot) const { return quiet_pool_ + (size_t)slot * 4 * (size_t)g_.qn; }
+    bool quiet_wanted(const Call &c, const ShotCtx &x) const { return c.opt.quiet_skip != 0 && (x.nrec == 0 || (x.line.n > 0 && c.opt.line_fuse != 0)); }
     float *syn_of(const ShotCtx &x, int comp) const { return x.syn + (size_t)comp * data_len_; }
     bool forward_inline(const Call &c, const ShotCtx &x) const { return x.line.n > 0 && !(x.comps & 1) && c.opt.line_fuse != 0; }
     // forward pass of one shot, stream form (libCUFD.cu:268-332)
@@ -170,6 +174,7 @@ class Session {
     PmlCoef pc_{};
     ImgAcc acc_{};
     std::unique_ptr<ObservedStore> obs_;
+    unsigned int *quiet_pool_ = nullptr;  // kQuietSlots x 4 maps of Grid::qn words (Fields::q)
     // persistent backward time loop: the tiling in use, its device copy, synchronisation words, what the census of the grid said
     struct Persist {
         PersistPlan plan;
@@ -185,6 +190,8 @@ class Session {
         int retry_in = 0, aborts = 0;    // passes until the loop is tried again after a start rendezvous that failed; how often it did
     } pk_;
     long long persist_steps_ = 0;
+    long long quiet_active_ = 0, quiet_total_ = 0;
+    unsigned int *quiet_last_ = nullptr;  // maps of the shot whose forward pass started last in this call
 
     double fwd_ms_ = 0, bwd_ms_ = 0, total_ms_ = 0;
     long long fwd_steps_ = 0, bwd_steps_ = 0, launches_ = 0;

@@ -106,6 +106,7 @@ void Session::use_state(ShotCtx &x, float *state) const {
     x.state = state;
     float *b = state;
     x.fld = Fields{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n};
+    x.fld.q = x.quiet;
     x.mem = PmlMem{b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n, b + 9 * n, b + 10 * n, b + 11 * n, b + 12 * n};
 }
 
@@ -133,6 +134,7 @@ Session::ShotCtx Session::make_ctx(const Call &c, int is, int lane, hipStream_t 
         x.line.x0 = sh.x_rec[0];
         x.line.n = x.nrec;
     }
+    x.quiet = quiet_wanted(c, x) ? quiet_slot(lane) : nullptr;
     use_state(x, lane ? xl_[lane].state : state_);
     x.frame = lane ? xl_[lane].frame : frame_;
     x.syn = lane ? xl_[lane].syn : syn_;
@@ -145,6 +147,10 @@ Session::ShotCtx Session::make_ctx(const Call &c, int is, int lane, hipStream_t 
 // zero the 5 fields + 8 memory variables (libCUFD.cu:175-194); data column 0 stays 0 (:205-209)
 void Session::forward_init(const ShotCtx &x) {
     HIP_OK(hipMemsetAsync(x.state, 0, 13 * cells_ * sizeof(float), x.st));
+    if (x.quiet) {
+        HIP_OK(hipMemsetAsync(x.quiet, 0, 2 * (size_t)g_.qn * sizeof(unsigned int), x.st));  // nothing holds a value yet
+        quiet_last_ = x.quiet;
+    }
     for (int k = 0; k < 4; k++)
         if ((x.comps >> k) & 1) HIP_OK(hipMemsetAsync(syn_of(x, k), 0, (size_t)x.nrec * sizeof(float), x.st));
 }
@@ -313,8 +319,10 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
     if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
     if (opt.bwd_fuse != 0) {
         hipEvent_t *ev = probe_pair(c, it);
-        launch_bwd_a(L.s, gs, opt, x.fld, L.bm, md_, pc_, frame_t, L.adj, L.acc);
-        launch_bwd_b(L.s, gs, opt, x.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, L.adj, L.acc, lr, ev ? ev[0] : nullptr,
+        Fields adj = L.adj;  // (the adjoint maps follow the shot's lane; the residual enters inside k_bwd_b, which marks the channels' segments)
+        adj.q = x.quiet ? x.quiet + 2 * (size_t)g.qn : nullptr;
+        launch_bwd_a(L.s, gs, opt, x.fld, L.bm, md_, pc_, frame_t, adj, L.acc);
+        launch_bwd_b(L.s, gs, opt, x.fld, L.bm, md_, pc_, frame_t, sh.z_src, sh.x_src, amp, (float)sh.src_rxz, sg, adj, L.acc, lr, ev ? ev[0] : nullptr,
                      ev ? ev[1] : nullptr);
         if (!inj_inl) launch_inject(L.s, g, L.adj, x.nrec, x.rec, res_t, x.sens);
         launches_ += inj_inl ? 2 : 3;
@@ -336,7 +344,7 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
 // channels need k_inject between the two halves of a step and never take the loop.
 bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     const KernelOptions &opt = c.opt;
-    if (opt.bwd_fuse != 4) return false;
+    if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
     if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
     Persist &k = pk_;
     if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
@@ -452,6 +460,7 @@ void Session::backward(Call &c, const ShotCtx &x) {
     const bool persistent = persist_ready(c, x);
     HIP_OK(hipEventRecord(ev_[2], st));
     backward_init(L);
+    if (x.quiet) HIP_OK(hipMemsetAsync(x.quiet + 2 * (size_t)g_.qn, 0, 2 * (size_t)g_.qn * sizeof(unsigned int), st));  // the adjoint maps
     if (persistent) {
         backward_persistent(c, x, L);
         HIP_OK(hipStreamSynchronize(st));
@@ -559,6 +568,7 @@ void Session::run_batched(Call &c, int Bf, int Bb) {
     auto lane_ctx = [&](int is, bool with_obs) {  // shot `is` of the call in its batch lane
         ShotCtx x = make_ctx(c, is, 0, st, with_obs);
         const BLane &L = bl_[is % Bf];
+        if (x.quiet) x.quiet = quiet_slot(kMaxLanes + is % Bf);
         use_state(x, L.state);
         x.frame = L.frame;
         x.syn = L.syn;
@@ -588,6 +598,7 @@ void Session::run_batched(Call &c, int Bf, int Bb) {
         d.comps = x.comps | ((lf && x.line.n > 0 && !(x.comps & 1)) ? 16 : 0);  // bit 16: sample the line inside k_stress
         d.nrec = x.nrec;
         d.src_rxz = (float)x.sh->src_rxz;
+        d.quiet = x.quiet;
     }
     HIP_OK(hipMemcpyAsync(d_shots_, tab.data(), tab.size() * sizeof(ShotDev), hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));  // `tab` and `stf_rows` are pageable host memory
@@ -627,6 +638,8 @@ void Session::run_batched(Call &c, int Bf, int Bb) {
             const int nbb = std::min(Bb, nb - kb);
             HIP_OK(hipEventRecord(ev_[2], st));
             for (int k = 0; k < nbb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd, 0, 13 * n * sizeof(float), st));  // memories + adjoint fields
+            for (int k = 0; k < nbb; k++)
+                if (cx[kb + k].quiet) HIP_OK(hipMemsetAsync(cx[kb + k].quiet + 2 * (size_t)g.qn, 0, 2 * (size_t)g.qn * sizeof(unsigned int), st));
             for (int it = nSteps - 2; it >= 0; it--) {
                 hipEvent_t *ev = probe_pair(c, it);
                 Grid gs = g;
@@ -705,6 +718,8 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     probe_us_ = 0.0;
     probe_calls_ = 0;
     fwd_steps_ = bwd_steps_ = persist_steps_ = 0;
+    quiet_active_ = quiet_total_ = 0;
+    quiet_last_ = nullptr;
     for (int i = 0; i < group_size; i++) {
         const int id = shot_ids[i];
         if (id < 0 || id >= (int)survey_.shots.size() || !survey_.shots[id].present)
@@ -747,6 +762,13 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     } else if (!ext_stream) {  // later work on the default stream sees this call's outputs
         HIP_OK(hipEventRecord(ev_order_, c.st));
         HIP_OK(hipStreamWaitEvent(nullptr, ev_order_, 0));
+    }
+    if (quiet_last_) {  // how much of the grid the last shot's forward field reached (sepfwi_stats)
+        std::vector<unsigned int> bits((size_t)g_.qn);
+        HIP_OK(hipMemcpyAsync(bits.data(), quiet_last_ + g_.qn, bits.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, c.st));
+        HIP_OK(hipStreamSynchronize(c.st));
+        for (unsigned int w : bits) quiet_active_ += __builtin_popcount(w);
+        quiet_total_ = (long long)(g_.nzc - 4) * ((g_.nx + 63) / 64);
     }
     total_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     last_shots_ = group_size;

@@ -25,7 +25,7 @@ class Stats(C.Structure):
                 ("cell_updates", C.c_double), ("fwd_steps", C.c_longlong), ("bwd_steps", C.c_longlong),
                 ("launches", C.c_longlong), ("device_bytes", C.c_longlong), ("n_c", C.c_int),
                 ("probe_kernel_us", C.c_double), ("probe_calls", C.c_longlong),
-                ("obs_device_bytes", C.c_longlong), ("obs_host_bytes", C.c_longlong), ("obs_evictions", C.c_longlong), ("persist_steps", C.c_longlong)]
+                ("obs_device_bytes", C.c_longlong), ("obs_host_bytes", C.c_longlong), ("obs_evictions", C.c_longlong), ("persist_steps", C.c_longlong), ("quiet_active", C.c_longlong), ("quiet_total", C.c_longlong)]
 
 
 def needs_build() -> bool:
