@@ -28,7 +28,7 @@ import bench  # noqa: E402  (kernel_source_digest)
 
 fetch = parse(os.path.join(ROOT, "profiles", "%s_bench_pmc_fetch.txt" % TAG), "FETCH_SIZE")
 write = parse(os.path.join(ROOT, "profiles", "%s_bench_pmc_write.txt" % TAG), "WRITE_SIZE")
-keys = {"k_bwd_b": "k_bwd_b", "k_bwd_a": "k_bwd_a", "k_stress<true, true>": "k_stress_fwd_save", "k_velocity<true>": "k_velocity_fwd"}
+keys = {"k_bwd_b": "k_bwd_b", "k_bwd_a": "k_bwd_a", "k_stress<true, true, false>": "k_stress_fwd_save", "k_velocity<true, false>": "k_velocity_fwd"}
 res = {"_how": "rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE on `python bench.py --steps 1 --warmup 0 --nsteps 400 "
                "--no-cpu-baseline` (profiles/%s_bench_pmc_fetch.txt, %s_bench_pmc_write.txt); FETCH_SIZE doubled per the gfx950 "
                "correction of MI355X_MICROARCH.md (calibrated in round 1 on a kernel with known compulsory bytes: 10 arrays x 9.19 MB = 91.9 MB vs 2 x 45.1 MB "
