@@ -68,3 +68,37 @@ def test_quiet_skip_on_other_geometries(tmp_path, hip_ops, geo):
     for name, a, b in zip(_NAMES, outs[0], outs[1]):
         assert np.array_equal(a, b), (geo, name, float(np.abs(a - b).max()), float(np.abs(a).max()))
     assert np.abs(outs[0][1]).max() > 0
+
+
+_SEEDS = list(range(int(os.environ.get("SEPFWI_QFUZZ_N", "5"))))
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_quiet_skip_random_geometry(tmp_path, hip_ops, seed):
+    """Seeded random grids, layer widths, record lengths, source and fibre depths, launch structures: with and without the option the
+    same bits.  One-off sweeps: SEPFWI_QFUZZ_N=300 (profiles/r05_quiet_fuzz.txt)."""
+    rng = np.random.default_rng(7000 + seed)
+    nPml = int(rng.integers(6, 33))
+    nz, nx = int(rng.integers(40, 500)), int(rng.integers(100, 1500))
+    nPad = int(rng.integers(0, 9))
+    nSteps = int(rng.integers(120, 500))
+    nshots = int(rng.integers(1, 4))
+    pb = P.make_problem(str(tmp_path), nz=nz, nx=nx, nPml=nPml, nPad=nPad, nSteps=nSteps, nshots=nshots, hetero=True, seed=seed,
+                        src_z=int(rng.integers(1, 5)), rec_z=int(rng.integers(2, max(3, min(nz - 3, 50)))), f0=float(rng.uniform(10.0, 30.0)))
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"], to_store=True)
+    lam, mu, den = pb["lame_init"]
+    lam = (lam * 1.05).contiguous()
+    mode = dict(batch=int(rng.choice([0, 0, 1])), img_every=int(rng.choice([1, 1, 2])), bz=int(rng.choice([1, 2, 2, 4])), xcd_remap=int(rng.integers(0, 2)),
+                rho_fly=int(rng.choice([1, 1, 0, 3])), pair_fwd=int(rng.integers(0, 2)))
+    outs = []
+    for q in (0, 1):
+        with P.kernel_options(quiet_skip=q, **mode):
+            outs.append([t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])])
+            st = hip_ops.stats(pb["para_fname"], 0)
+    hip_ops.release()
+    desc = dict(seed=seed, nz=nz, nx=nx, nPml=nPml, nPad=nPad, nSteps=nSteps, nshots=nshots, **mode)
+    assert st["quiet_total"] > 0 and st["quiet_active"] > 0, desc
+    for name, a, b in zip(_NAMES, outs[0], outs[1]):
+        assert np.array_equal(a, b), (desc, name, float(np.abs(a - b).max()), float(np.abs(a).max()))
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][4]).max() > 0, desc
