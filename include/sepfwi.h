@@ -150,7 +150,8 @@ int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
  * (k > 1: the imaging condition on every k-th backward step with weight k dt -- an opt-in quadrature of the same time integrals,
  * gradients within 1e-4 of every-step imaging for the usual wavelets; NOT covered by the next sentence), obs_cache_mb 0,
  * quiet_skip 0 (1: updates of 64-cell row segments whose every input is exactly +0 -- the fields ahead of the wave front -- are left
- * out; bit-identical results; shots whose channels are a line, forward kernels and the two-launch backward step).
+ * out; bit-identical results; shots whose channels are a line, forward kernels and the two-launch backward step),
+ * quiet_rows 4 (rows per wave of the forward kernels while quiet_skip is on).
  * sepfwi_set_option edits the process-wide defaults under a lock; every sepfwi_cufd* call takes ONE snapshot of them when
  * it starts, so a call never sees a half-changed block and concurrent calls on other GPUs are unaffected.  Results are
  * identical (to the parity tolerances) for every setting.  Returns SEPFWI_EINVAL for unknown names or values;

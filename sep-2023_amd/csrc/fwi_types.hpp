@@ -38,6 +38,7 @@ struct Grid {
     int amu_fly;  // 1: the 4-point harmonic mean of mu recomputed from mu in the stress-type kernels
     int nb, shot_fastest;  // batched launches: shots per grid and the order of (tile, shot) in the block index
     int nblk;     // blocks of the launch in the logical numbering (my_cell)
+    int qr;       // quiet-skipping kernels: consecutive rows per wave (a quiet wave costs its dispatch whatever it skips)
     int qzw, qn;  // quiet-segment bit maps (option quiet_skip, Fields::q): 32-bit words per segment column, words per map
 };
 

@@ -632,9 +632,72 @@ __device__ __forceinline__ void q_mark(unsigned int *q, const Grid &g, int z, in
         atomicOr(&q[(size_t)(xs + 1) * (size_t)g.qzw + (size_t)(r >> 5)], 1u << (r & 31));
     }
 }
+// quiet-skipping kernels: a wave owns g.qr consecutive rows; its r-th (the row stays wave-uniform: scalar profile loads and PML tests)
+__device__ __forceinline__ Cell row_of(const Grid &g, Cell c, int r) {
+    c.z = __builtin_amdgcn_readfirstlane(c.z * g.qr + r);
+    c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
+    return c;
+}
 __device__ __forceinline__ int seg_of(const Cell &c) { return __builtin_amdgcn_readfirstlane(c.x) >> 6; }
 
-// The four updates with their maps.  (ONE instance of each body, whatever the option says: two would double the kernels' code.)
+// The four updates with their maps: DECIDE (read the maps; wave-uniform, scalar loads only), then the body, then the own bit.
+// (Deciding for both updates of a fused backward kernel before applying either measured 1 us slower per step, not faster.)
+struct QDec {
+    bool on, own, quiet, no_img;
+    int xs;
+};
+template <bool FWD>
+__device__ __forceinline__ QDec q_dec_stress(const Grid &g, const Cell &c, const Fields &f, const Fields &adj, int z_src, int x_src, float src_amp) {
+    QDec d{false, true, false, false, 0};
+    const int z = c.z;
+    d.on = f.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    if (d.on) {
+        d.xs = seg_of(c);
+        d.own = q_bit(f.q + g.qn, g, z, d.xs) != 0;
+        const bool src = z == z_src && (x_src >> 6) == d.xs && src_amp != 0.0f;
+        d.quiet = !(d.own || src || q_reach(f.q, g, z, d.xs) != 0);
+        d.no_img = !FWD && adj.q && q_bit(adj.q + g.qn, g, z, d.xs) == 0;
+    }
+    return d;
+}
+template <bool FWD>
+__device__ __forceinline__ QDec q_dec_velocity(const Grid &g, const Cell &c, const Fields &f, const Fields &adj) {
+    QDec d{false, true, false, false, 0};
+    const int z = c.z;
+    d.on = f.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    if (d.on) {
+        d.xs = seg_of(c);
+        d.own = q_bit(f.q, g, z, d.xs) != 0;
+        d.quiet = !(d.own || q_reach(f.q + g.qn, g, z, d.xs) != 0);
+        d.no_img = !FWD && adj.q && q_bit(adj.q, g, z, d.xs) == 0;
+    }
+    return d;
+}
+__device__ __forceinline__ QDec q_dec_velocity_adj(const Grid &g, const Cell &c, const Fields &adj, const LineRec &lr) {
+    QDec d{false, true, false, false, 0};
+    const int z = c.z;
+    d.on = adj.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    if (d.on) {
+        d.xs = seg_of(c);
+        d.own = q_bit(adj.q, g, z, d.xs) != 0;
+        // the residual of the step is injected into cells lr.x0 - 1 ... lr.x0 + lr.n - 1 of row lr.z
+        const bool rec = lr.n && z == lr.z && d.xs * BX + BX - 1 >= lr.x0 - 1 && d.xs * BX <= lr.x0 + lr.n - 1;
+        d.quiet = !(d.own || rec || q_reach(adj.q + g.qn, g, z, d.xs) != 0);
+    }
+    return d;
+}
+__device__ __forceinline__ QDec q_dec_stress_adj(const Grid &g, const Cell &c, const Fields &adj) {
+    QDec d{false, true, false, false, 0};
+    const int z = c.z;
+    d.on = adj.q != nullptr && z >= 2 && z <= g.nzc - 3;
+    if (d.on) {
+        d.xs = seg_of(c);
+        d.own = q_bit(adj.q + g.qn, g, z, d.xs) != 0;
+        d.quiet = !(d.own || q_reach(adj.q, g, z, d.xs) != 0);
+    }
+    return d;
+}
+
 template <bool Q, bool FWD, bool SAVE, class ACC>
 __device__ __forceinline__ void stress_update(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md, const PmlCoef &pc,
                                               float *__restrict__ frame_t, int z_src, int x_src, float src_amp, const Fields &adj,
@@ -643,19 +706,9 @@ __device__ __forceinline__ void stress_update(const Grid &g, const Cell &c, cons
         stress_body<FWD, SAVE>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr);
         return;
     }
-    const int z = c.z;
-    const bool on = f.q != nullptr && z >= 2 && z <= g.nzc - 3;
-    bool own = true, quiet = false, no_img = false;
-    int xs = 0;
-    if (on) {
-        xs = seg_of(c);
-        own = q_bit(f.q + g.qn, g, z, xs) != 0;
-        const bool src = z == z_src && (x_src >> 6) == xs && src_amp != 0.0f;
-        quiet = !(own || src || q_reach(f.q, g, z, xs) != 0);
-        no_img = !FWD && adj.q && q_bit(adj.q + g.qn, g, z, xs) == 0;
-    }
-    const bool nz = stress_body<FWD, SAVE>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr, quiet, no_img);
-    if (on) q_mark(f.q + g.qn, g, z, xs, nz, own);
+    const QDec d = q_dec_stress<FWD>(g, c, f, adj, z_src, x_src, src_amp);
+    const bool nz = stress_body<FWD, SAVE>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, acc, lr, d.quiet, d.no_img);
+    if (d.on) q_mark(f.q + g.qn, g, c.z, d.xs, nz, d.own);
 }
 template <bool Q, bool FWD, class ACC>
 __device__ __forceinline__ void velocity_update(const Grid &g, const Cell &c, const Fields &f, const PmlMem &m, const Media &md, const PmlCoef &pc,
@@ -665,18 +718,9 @@ __device__ __forceinline__ void velocity_update(const Grid &g, const Cell &c, co
         velocity_body<FWD>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc);
         return;
     }
-    const int z = c.z;
-    const bool on = f.q != nullptr && z >= 2 && z <= g.nzc - 3;
-    bool own = true, quiet = false, no_img = false;
-    int xs = 0;
-    if (on) {
-        xs = seg_of(c);
-        own = q_bit(f.q, g, z, xs) != 0;
-        quiet = !(own || q_reach(f.q + g.qn, g, z, xs) != 0);
-        no_img = !FWD && adj.q && q_bit(adj.q, g, z, xs) == 0;
-    }
-    const bool nz = velocity_body<FWD>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc, quiet, no_img);
-    if (on) q_mark(f.q, g, z, xs, nz, own);
+    const QDec d = q_dec_velocity<FWD>(g, c, f, adj);
+    const bool nz = velocity_body<FWD>(g, c, f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, acc, d.quiet, d.no_img);
+    if (d.on) q_mark(f.q, g, c.z, d.xs, nz, d.own);
 }
 template <bool Q>
 __device__ __forceinline__ void velocity_adj_update(const Grid &g, const Cell &c, const Fields &adj, const PmlMem &m, const Media &md,
@@ -685,19 +729,9 @@ __device__ __forceinline__ void velocity_adj_update(const Grid &g, const Cell &c
         velocity_adj_body(g, c, adj, m, md, pc, lr);
         return;
     }
-    const int z = c.z;
-    const bool on = adj.q != nullptr && z >= 2 && z <= g.nzc - 3;
-    bool own = true, quiet = false;
-    int xs = 0;
-    if (on) {
-        xs = seg_of(c);
-        own = q_bit(adj.q, g, z, xs) != 0;
-        // the residual of the step is injected into cells lr.x0 - 1 ... lr.x0 + lr.n - 1 of row lr.z
-        const bool rec = lr.n && z == lr.z && xs * BX + BX - 1 >= lr.x0 - 1 && xs * BX <= lr.x0 + lr.n - 1;
-        quiet = !(own || rec || q_reach(adj.q + g.qn, g, z, xs) != 0);
-    }
-    const bool nz = velocity_adj_body(g, c, adj, m, md, pc, lr, quiet);
-    if (on) q_mark(adj.q, g, z, xs, nz, own);
+    const QDec d = q_dec_velocity_adj(g, c, adj, lr);
+    const bool nz = velocity_adj_body(g, c, adj, m, md, pc, lr, d.quiet);
+    if (d.on) q_mark(adj.q, g, c.z, d.xs, nz, d.own);
 }
 template <bool Q>
 __device__ __forceinline__ void stress_adj_update(const Grid &g, const Cell &c, const Fields &adj, const PmlMem &m, const Media &md,
@@ -706,17 +740,9 @@ __device__ __forceinline__ void stress_adj_update(const Grid &g, const Cell &c, 
         stress_adj_body(g, c, adj, m, md, pc);
         return;
     }
-    const int z = c.z;
-    const bool on = adj.q != nullptr && z >= 2 && z <= g.nzc - 3;
-    bool own = true, quiet = false;
-    int xs = 0;
-    if (on) {
-        xs = seg_of(c);
-        own = q_bit(adj.q + g.qn, g, z, xs) != 0;
-        quiet = !(own || q_reach(adj.q, g, z, xs) != 0);
-    }
-    const bool nz = stress_adj_body(g, c, adj, m, md, pc, quiet);
-    if (on) q_mark(adj.q + g.qn, g, z, xs, nz, own);
+    const QDec d = q_dec_stress_adj(g, c, adj);
+    const bool nz = stress_adj_body(g, c, adj, m, md, pc, d.quiet);
+    if (d.on) q_mark(adj.q + g.qn, g, c.z, d.xs, nz, d.own);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,13 +751,25 @@ __device__ __forceinline__ void stress_adj_update(const Grid &g, const Cell &c, 
 template <bool FWD, bool SAVE, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_stress(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc, float *__restrict__ frame_t,
                                                  int z_src, int x_src, float src_amp, Fields adj, ImgAcc acc, LineRec lr) {
-    stress_update<Q, FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
+    if constexpr (Q) {
+        const Cell c0 = my_cell(g);
+        for (int r = 0; r < g.qr; r++)
+            stress_update<Q, FWD, SAVE>(g, row_of(g, c0, r), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
+    } else {
+        stress_update<Q, FWD, SAVE>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_amp, adj, AccG{acc}, lr);
+    }
 }
 template <bool FWD, bool Q = false>
 __global__ __launch_bounds__(MAXT) void k_velocity(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc,
                                                    const float *__restrict__ frame_t, int z_src, int x_src, float src_rxz,
                                                    float *__restrict__ stf_grad_it, Fields adj, ImgAcc acc) {
-    velocity_update<Q, FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
+    if constexpr (Q) {
+        const Cell c0 = my_cell(g);
+        for (int r = 0; r < g.qr; r++)
+            velocity_update<Q, FWD>(g, row_of(g, c0, r), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
+    } else {
+        velocity_update<Q, FWD>(g, my_cell(g), f, m, md, pc, frame_t, z_src, x_src, src_rxz, stf_grad_it, adj, AccG{acc});
+    }
 }
 __global__ __launch_bounds__(MAXT) void k_velocity_adj(Grid g, Fields f, PmlMem m, Media md, PmlCoef pc) {
     velocity_adj_body(g, my_cell(g), f, m, md, pc, LineRec{});
@@ -788,7 +826,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd_a(Grid g, BwdArgs b, const float *
     const ImgAcc acc = acc_of(b.acc, b.n);
     const PmlCoef pc = coef_of(b.cz, b.cz + 6 * g.nzc, g.nzc, g.nx);
     const Cell c = my_cell(g);
-    if constexpr (Q) {
+    if constexpr (Q) {  // (one row per wave here: a loop over rows pushes these kernels into scalar-register spills)
         velocity_update<Q, false>(g, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, AccG{acc});
         stress_adj_update<Q>(g, c, adj, m, md, pc);
         return;
@@ -1375,7 +1413,7 @@ const OptField kOptFields[] = {
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
-    {"quiet_skip", &KernelOptions::quiet_skip, 0, 1},
+    {"quiet_skip", &KernelOptions::quiet_skip, 0, 1}, {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
     {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
 };
@@ -1401,11 +1439,12 @@ int set_kernel_option(const char *name, int value) {
     return -1;
 }
 
-static inline Grid tiled(const Grid &g0, const KernelOptions &o, int fly_bit = -1) {
+static inline Grid tiled(const Grid &g0, const KernelOptions &o, int fly_bit = -1, bool quiet = false) {
     Grid g = g0;
     g.bz = o.bz;
+    g.qr = quiet ? o.quiet_rows : 1;
     g.gx = (g.nx + BX - 1) / BX;
-    g.gy = (g.nzc + g.bz - 1) / g.bz;
+    g.gy = (g.nzc + g.bz * g.qr - 1) / (g.bz * g.qr);
     g.xcd_remap = o.xcd_remap;
     g.rho_fly = fly_bit < 0 ? 0 : (o.rho_fly >> fly_bit) & 1;
     g.amu_fly = fly_bit < 0 ? 0 : (o.amu_fly >> fly_bit) & 1;
@@ -1419,7 +1458,7 @@ static inline dim3 field_grid(const Grid &g) { return dim3(g.nblk); }
 
 void launch_stress_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc,
                        float *frame_t, int z_src, int x_src, float src_amp, LineRec lr) {
-    const Grid g = tiled(g0, o, 0);
+    const Grid g = tiled(g0, o, 0, f.q != nullptr);
     Fields none{};
     ImgAcc na{};
     auto k = frame_t ? (f.q ? k_stress<true, true, true> : k_stress<true, true, false>) : (f.q ? k_stress<true, false, true> : k_stress<true, false, false>);
@@ -1427,7 +1466,7 @@ void launch_stress_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, F
 }
 
 void launch_velocity_fwd(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields f, PmlMem m, Media md, PmlCoef pc) {
-    const Grid g = tiled(g0, o, 0);
+    const Grid g = tiled(g0, o, 0, f.q != nullptr);
     Fields none{};
     ImgAcc na{};
     auto k = f.q ? k_velocity<true, true> : k_velocity<true, false>;

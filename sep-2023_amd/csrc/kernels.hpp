@@ -28,6 +28,7 @@ struct KernelOptions {
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
     int quiet_skip = 0;   // 1: updates of row segments whose every input is exactly +0 are left out (the fields ahead of the wave front; same bits).
                           // Used by the forward kernels and the two-launch backward step; line receivers (or none) only
+    int quiet_rows = 4;   //   rows per wave of the quiet-skipping FORWARD kernels (a quiet wave costs its dispatch whatever it skips)
     int obs_cache_mb = 0; // HBM budget [MB] of the observed-data store (0: unlimited; a parameter-file key of the same name wins)
     // persistent backward time loop (bwd_fuse = 4; kernels.hip k_bwd_persist)
     int pk_lmask = 16;    //   imaging accumulators kept in LDS: bit 0 lam, 1 mu, 2 xz, 3 a (16: as many as fit, in that order)
