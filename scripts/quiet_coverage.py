@@ -16,6 +16,9 @@ from sepfwi import _native, fwi_ops
 
 def main():
     L = _native.lib()
+    for kv in os.environ.get("QC_OPTS", "").split(","):      # e.g. QC_OPTS=pair_fwd=0,batch=0
+        if kv:
+            _native.check(L.sepfwi_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
     dev = torch.device("cuda", 0)
     for nsteps in [int(a) for a in sys.argv[1:]] or [1000, 4000]:
         work = tempfile.mkdtemp(prefix="sepfwi_qc_")
