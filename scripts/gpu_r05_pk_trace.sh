@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 5: wave timeline of the persistent loop (one-off build with -DSEPFWI_PK_TRACE on the GPU box; the shipped library is not traced)
+mkdir -p gpurun_out
+cd sep-2023_amd && SEPFWI_HIPCC_FLAGS=-DSEPFWI_PK_TRACE python -c "from sepfwi import _native; _native.build(force=True)" > ../gpurun_out/pk_trace_build.log 2>&1 || { tail -5 ../gpurun_out/pk_trace_build.log; exit 1; }
+cd ..
+for V in "$@"; do
+  echo "== variant: $V"
+  SEPFWI_PK_TRACE=$PWD/gpurun_out/pk_trace.bin timeout -k 10 300 python scripts/ab_bench.py --nsteps 400 --rounds 1 --shots 1 "$V" 2>&1 | grep -v amdgpu.ids
+  python scripts/pk_trace.py gpurun_out/pk_trace.bin
+done
+rm -f gpurun_out/pk_trace.bin

@@ -135,6 +135,7 @@ struct PersistArgs {
     int *err;                // 0, 1 a wait inside the pass timed out
     int phase0;              // phases of the pass done by earlier launches
     int nosync;              // timing experiments only: no waits, no flags, no agent-scope accesses (results wrong)
+    int prio;                // 1: wave priorities interleave the CU's two workgroups (kernels.hip)
 };
 
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step

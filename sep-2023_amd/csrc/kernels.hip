@@ -28,6 +28,9 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -1007,7 +1010,24 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
 //   * the pass starts with a rendezvous of the whole grid (below): if the grid is not resident at once, or a band is spread over
 //     several XCDs, every workgroup leaves before anything is touched and the host runs the two-launch step instead.
 //   * every spin is bounded; a time-out later in the pass raises *err, every workgroup leaves, the host reports it.
+// Two things the wave timeline showed (profiles/r05_pk_trace.txt): tiles wait for their neighbours every phase, so the slowest tile
+// sets the pace of all --
+//   * the instruction arbiter serves the OLDEST wave first, and in a launch that never ends the CU's first workgroup stays the older
+//     one: its tile ran a third faster than the second workgroup's (17 against 26 us per phase).  Wave priorities (s_setprio) are
+//     therefore dealt so that the two workgroups interleave -- each has half of its waves on the upper pair of levels, and which
+//     workgroup gets the odd levels alternates from phase to phase (option pk_prio);
+//   * tiles that own the x C-PML strips execute the absorbing-layer branches (twice the loads): the host-built tiling cuts by cost,
+//     not by count (persist_plan.hpp PlanCost, options pk_wx / pk_wz).
+// Segment descriptors are read through the scalar cache: a vector load of one waits with vmcnt(0), i.e. for the previous row segment's
+// stores as well (2.6 % of the backward step).
 // ---------------------------------------------------------------------------------------------
+#ifdef SEPFWI_PK_TRACE
+// one-off wave timeline of the loop (build with SEPFWI_HIPCC_FLAGS=-DSEPFWI_PK_TRACE; scripts/gpu_r05_pk_trace.sh, scripts/pk_trace.py):
+// per (tile, wave, phase 200..207 of the launch) s_memrealtime at the phase start (after the barrier), at each item start (up to 8), at
+// the end of the wave's items and after the closing drain.  Written to pinned host memory, dumped to $SEPFWI_PK_TRACE at exit.
+__device__ unsigned long long *g_pk_trace;
+constexpr int kTrTiles = 512, kTrPh0 = 200, kTrPh = 8, kTrSlots = 12;
+#endif
 constexpr int kPersistSpinLimit = 1 << 21;   // polls of ~1 us: about two seconds (never reached once the start rendezvous has passed)
 constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 
@@ -1015,7 +1035,7 @@ constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 template <int LMASK>
 __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
     extern __shared__ float lds_dyn[];
-    __shared__ int next_item, edge_done, abort_flag, start_verdict;
+    __shared__ int next_item, edge_done, abort_flag, start_verdict, cu_slot_s;
     const ShotDev &s = a.s;
     const size_t n = a.n;
     const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
@@ -1025,7 +1045,8 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
     const int band = (int)(blockIdx.x % a.nband);
     const int tile = band * a.per_band + (int)(blockIdx.x / a.nband);
     const TileHdr &h = a.hdr[tile];
-    const uint32_t *__restrict__ segs = a.seg + (size_t)tile * (size_t)a.cap;
+    typedef const uint32_t __attribute__((address_space(4))) *seg_table_t;  // constant for the launch: scalar loads
+    const seg_table_t segs = (seg_table_t)(a.seg + (size_t)tile * (size_t)a.cap);
     const int nst = h.n_seg, n_edge = h.n_edge, nnb = h.n_nb;
     const int lane = threadIdx.x & (BX - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
@@ -1056,9 +1077,23 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             }
         }
         start_verdict = (int)verdict;
+        // first or second workgroup on this CU?  (arrival order at a per-CU counter kept in the spare words of the flag lines)
+        const unsigned int hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_REG_HW_ID: bits 8..15 = CU, shader array, engine
+        const unsigned int xcc_ = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID
+        const unsigned int key = (xcc_ << 8) | ((hwid >> 8) & 0xffu);
+        cu_slot_s = (int)atomicAdd(a.flags + (size_t)(key % gridDim.x) * 32 + 1 + (key / gridDim.x) % 31, 1u);
     }
     __syncthreads();  // (all waves keep their registers meanwhile: a workgroup reduced to one wave would make room for one that does not fit)
     if (start_verdict != (int)kPersistGo) return;
+    const int cu_slot = cu_slot_s;
+    auto set_prio = [&](int p) {  // (the instruction takes an immediate)
+        switch (p & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
     auto cell_of = [&](uint32_t d) {
         Cell c;
         c.z = __builtin_amdgcn_readfirstlane((int)(d & 0xffffu));
@@ -1127,6 +1162,16 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             }
             const int base = local * nst;
             bool reported = false;
+            // waves w, w+4, w+8, w+12 of a workgroup share a SIMD: two of them on levels {2, 3}, two on {0, 1}; the odd levels go to
+            // the CU's first workgroup in even phases and to the second in odd ones
+            if (a.prio) set_prio(2 * ((wave >> 2) & 1) + ((cu_slot ^ local) & 1));
+#ifdef SEPFWI_PK_TRACE
+            unsigned long long *tr = nullptr;
+            int tr_k = 1;
+            if (g_pk_trace && tile < kTrTiles && wave < 16 && local >= kTrPh0 && local < kTrPh0 + kTrPh && a.phase0 == 0)
+                tr = g_pk_trace + (((size_t)tile * 16 + wave) * kTrPh + (local - kTrPh0)) * kTrSlots;
+            if (tr && lane == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+#endif
             // a wave that has seen its last edge segment of the phase waits for its stores, counts itself in; the last one publishes
             auto report = [&]() {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1139,6 +1184,9 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             };
             for (; w < base + nst; w = grab()) {
                 const int j = w - base;
+#ifdef SEPFWI_PK_TRACE
+                if (tr && lane == 0 && tr_k < 9) tr[tr_k++] = __builtin_amdgcn_s_memrealtime();
+#endif
                 if (j >= n_edge && !reported) report();
                 const uint32_t d = segs[j];
                 const Cell c = cell_of(d);
@@ -1165,8 +1213,17 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                     }
                 }
             }
+#ifdef SEPFWI_PK_TRACE
+            if (tr && lane == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (!reported) report();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the phase are complete before the next barrier
+#ifdef SEPFWI_PK_TRACE
+            if (tr && lane == 0) {
+                tr[10] = __builtin_amdgcn_s_memrealtime();
+                tr[11] = (unsigned long long)tr_k;
+            }
+#endif
         }
     }
     __syncthreads();
@@ -1433,6 +1490,7 @@ const OptField kOptFields[] = {
     {"quiet_skip", &KernelOptions::quiet_skip, 0, 1}, {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
     {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
+    {"pk_prio", &KernelOptions::pk_prio, 0, 1}, {"pk_wx", &KernelOptions::pk_wx, 25, 400}, {"pk_wz", &KernelOptions::pk_wz, 25, 400},
 };
 }  // namespace
 
@@ -1590,6 +1648,24 @@ int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, c
     const Grid g = tiled(g0, o, 1);
     auto k = persist_kernel(lmask);
     if (!k) return -1;
+#ifdef SEPFWI_PK_TRACE
+    {
+        static unsigned long long *h_tr = nullptr;
+        static size_t tr_n = (size_t)kTrTiles * 16 * kTrPh * kTrSlots;
+        if (!h_tr && getenv("SEPFWI_PK_TRACE")) {
+            (void)hipHostMalloc((void **)&h_tr, tr_n * sizeof(unsigned long long), hipHostMallocDefault);
+            memset(h_tr, 0, tr_n * sizeof(unsigned long long));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pk_trace), &h_tr, sizeof(h_tr));
+            atexit([] {
+                (void)hipDeviceSynchronize();
+                if (FILE *fp = fopen(getenv("SEPFWI_PK_TRACE"), "wb")) {
+                    fwrite(h_tr, sizeof(unsigned long long), tr_n, fp);
+                    fclose(fp);
+                }
+            });
+        }
+    }
+#endif
     const int rc = persist_config_ok((const void *)k, nwg, threads, lds_bytes);
     if (rc) return rc;
     if (ev_start)

@@ -5,7 +5,7 @@
 
 namespace sepfwi {
 
-std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first) {
+std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first, const PlanCost &cost) {
     PersistPlan &p = *out;
     p = PersistPlan{};
     if (nzc < 1 || nseg < 1 || nwg < 1 || nband < 1 || strip_w < 1) return "persist plan: bad arguments";
@@ -19,23 +19,53 @@ std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w
     p.strip_w = strip_w;
     p.owner.assign((size_t)nzc * nseg, -1);
     std::vector<std::vector<uint32_t>> tiles(nwg);
+    // cost of a segment in percent of a plain one (100 everywhere without weights: the runs are then equal in length)
+    auto seg_cost = [&](int z, int xs) -> long long {
+        long long w = 100;
+        if (cost.nx > 0) {
+            const int x0 = xs * 64, x1 = std::min(cost.nx, x0 + 64) - 1;
+            if (x0 < cost.npml || x1 > cost.nx - cost.npml - 1) w = w * cost.w_xpml / 100;
+            if (z < cost.npml || z > nzc - cost.npml - 1) w = w * cost.w_zpml / 100;
+        }
+        return std::max(1LL, w);
+    };
+    // rows per band: equal, or in inverse proportion to the band weights
+    std::vector<int> row0(nband + 1, 0);
+    {
+        double tot = 0.0;
+        for (int b = 0; b < nband; b++) tot += 100.0 / (double)((cost.band_w && cost.band_w[b] > 0) ? cost.band_w[b] : 100);
+        double acc = 0.0;
+        for (int b = 0; b < nband; b++) {
+            row0[b] = (int)(acc / tot * nzc + 0.5);
+            acc += 100.0 / (double)((cost.band_w && cost.band_w[b] > 0) ? cost.band_w[b] : 100);
+        }
+        row0[nband] = nzc;
+        for (int b = 0; b < nband; b++)
+            if (row0[b + 1] <= row0[b]) return "persist plan: a band without rows";
+    }
     for (int b = 0; b < nband; b++) {
-        const int r0 = (int)((long long)nzc * b / nband), r1 = (int)((long long)nzc * (b + 1) / nband);
-        const long long len = (long long)(r1 - r0) * nseg;
-        long long k = 0;  // position in the band's strip-by-strip sequence
+        const int r0 = row0[b], r1 = row0[b + 1];
+        long long total = 0;
+        for (int z = r0; z < r1; z++)
+            for (int xs = 0; xs < nseg; xs++) total += seg_cost(z, xs);
+        long long k = 0;  // cost of the band's strip-by-strip sequence before this segment
         int strip = 0;
         for (int s0 = 0; s0 < nseg; s0 += strip_w, strip++) {
             const int s1 = std::min(nseg, s0 + strip_w);
             for (int rr = 0; rr < r1 - r0; rr++) {
                 const int z = (strip & 1) ? r1 - 1 - rr : r0 + rr;  // alternate direction: a run that crosses strips stays compact
-                for (int xs = s0; xs < s1; xs++, k++) {
-                    const int t = b * p.per_band + (int)(k * p.per_band / len);
+                for (int xs = s0; xs < s1; xs++) {
+                    const long long w = seg_cost(z, xs);
+                    const int t = b * p.per_band + (int)std::min<long long>(p.per_band - 1, (k + w / 2) * p.per_band / total);
+                    k += w;
                     p.owner[(size_t)z * nseg + xs] = t;
                     tiles[t].push_back((uint32_t)z | ((uint32_t)xs << 16));
                 }
             }
         }
     }
+    for (int t = 0; t < nwg; t++)
+        if (tiles[t].empty()) return "persist plan: a tile without segments";
     p.hdr.assign(nwg, TileHdr{});
     size_t cap = 1;
     for (int t = 0; t < nwg; t++) cap = std::max(cap, tiles[t].size());

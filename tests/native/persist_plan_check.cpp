@@ -12,10 +12,12 @@
 
 using namespace sepfwi;
 
-static int check(int nzc, int nseg, int nwg, int nband, int sw) {
+// cost = nullptr: plain tiling (tiles balanced by count); else by cost (PlanCost: the C-PML strips weigh more)
+static int check(int nzc, int nseg, int nwg, int nband, int sw, const PlanCost *cost = nullptr) {
     PersistPlan p;
-    const std::string why = make_persist_plan(nzc, nseg, nwg, nband, sw, &p);
-    if (!why.empty()) return why.find("neighbours") != std::string::npos ? 2 : -1;  // refused (legitimately: too many neighbours) or bad arguments
+    const std::string why = cost ? make_persist_plan(nzc, nseg, nwg, nband, sw, &p, true, *cost) : make_persist_plan(nzc, nseg, nwg, nband, sw, &p);
+    if (!why.empty())  // refused (legitimately: too many neighbours, more tiles than segments) or bad arguments
+        return (why.find("neighbours") != std::string::npos || why.find("without") != std::string::npos) ? 2 : -1;
     std::vector<int> seen((size_t)nzc * nseg, 0);
     int mn = 1 << 30, mx = 0;
     std::vector<std::set<int>> nbs(nwg);
@@ -50,14 +52,30 @@ static int check(int nzc, int nseg, int nwg, int nband, int sw) {
     for (int t = 0; t < nwg; t++)
         for (int o : nbs[t])
             if (o < 0 || o >= nwg || !nbs[o].count(t)) return 16;  // symmetric
-    // balanced inside every band (bands differ by at most one row of segments)
-    for (int b = 0; b < nband; b++) {
-        int lo = 1 << 30, hi = 0;
-        for (int t = b * p.per_band; t < (b + 1) * p.per_band; t++) {
-            lo = std::min(lo, p.hdr[t].n_seg);
-            hi = std::max(hi, p.hdr[t].n_seg);
+    // balanced inside every band (bands differ by at most one row of segments): by count, or by cost to within two segments
+    auto seg_cost = [&](int z, int xs) -> long long {
+        long long w = 100;
+        if (cost && cost->nx > 0) {
+            const int x0 = xs * 64, x1 = std::min(cost->nx, x0 + 64) - 1;
+            if (x0 < cost->npml || x1 > cost->nx - cost->npml - 1) w = w * cost->w_xpml / 100;
+            if (z < cost->npml || z > nzc - cost->npml - 1) w = w * cost->w_zpml / 100;
         }
-        if (hi - lo > 1) return 17;
+        return std::max(1LL, w);
+    };
+    for (int b = 0; b < nband; b++) {
+        long long lo = 1LL << 60, hi = 0, wmax = 0;
+        for (int t = b * p.per_band; t < (b + 1) * p.per_band; t++) {
+            long long c = 0;
+            for (int j = 0; j < p.hdr[t].n_seg; j++) {
+                const uint32_t d = p.seg[(size_t)t * p.cap + j];
+                const long long w = cost ? seg_cost((int)(d & 0xffffu), (int)((d >> 16) & 0xffu)) : 1;
+                c += w;
+                wmax = std::max(wmax, w);
+            }
+            lo = std::min(lo, c);
+            hi = std::max(hi, c);
+        }
+        if (hi - lo > (cost ? 2 * wmax : 1)) return 17;
     }
     return 0;
 }
@@ -74,7 +92,18 @@ int main(int argc, char **argv) {
     for (int it = 0; it < n; it++) {
         const int nband = 1 << (rng() % 4), per = 1 + (int)(rng() % 70), nwg = nband * per;
         const int nzc = 1 + (int)(rng() % 700), nseg = 1 + (int)(rng() % 60), sw = 1 + (int)(rng() % 9);
-        rc = check(nzc, nseg, nwg, nband, sw);
+        PlanCost pc;
+        int bw[8];
+        const bool weighted = (rng() % 2) != 0;
+        if (weighted) {
+            pc.nx = std::max(1, nseg * 64 - (int)(rng() % 64));
+            pc.npml = (int)(rng() % 70);
+            pc.w_xpml = 25 + (int)(rng() % 300);
+            pc.w_zpml = 25 + (int)(rng() % 300);
+            for (int b = 0; b < 8; b++) bw[b] = 60 + (int)(rng() % 100);
+            pc.band_w = (rng() % 2) ? bw : nullptr;
+        }
+        rc = check(nzc, nseg, nwg, nband, sw, weighted ? &pc : nullptr);
         if (rc == 0) ok++;
         else if (rc == 2) refused++;
         else { printf("FAIL nzc %d nseg %d nwg %d nband %d strip %d: %d\n", nzc, nseg, nwg, nband, sw, rc); return 1; }
