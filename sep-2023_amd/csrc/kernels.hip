@@ -1164,7 +1164,9 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             bool reported = false;
             // waves w, w+4, w+8, w+12 of a workgroup share a SIMD: two of them on levels {2, 3}, two on {0, 1}; the odd levels go to
             // the CU's first workgroup in even phases and to the second in odd ones
-            if (a.prio) set_prio(2 * ((wave >> 2) & 1) + ((cu_slot ^ local) & 1));
+            if (a.prio == 1) set_prio(2 * ((wave >> 2) & 1) + ((cu_slot ^ local) & 1));
+            else if (a.prio == 2) set_prio(2 * ((wave >> 2) & 1) + (cu_slot & 1));
+            else if (a.prio == 3) set_prio(2 * ((wave >> 2) & 1) + ((cu_slot ^ (local % 3 == 0)) & 1));
 #ifdef SEPFWI_PK_TRACE
             unsigned long long *tr = nullptr;
             int tr_k = 1;
@@ -1490,7 +1492,7 @@ const OptField kOptFields[] = {
     {"quiet_skip", &KernelOptions::quiet_skip, 0, 1}, {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
     {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
-    {"pk_prio", &KernelOptions::pk_prio, 0, 1}, {"pk_wx", &KernelOptions::pk_wx, 25, 400}, {"pk_wz", &KernelOptions::pk_wz, 25, 400},
+    {"pk_prio", &KernelOptions::pk_prio, 0, 3}, {"pk_wx", &KernelOptions::pk_wx, 25, 400}, {"pk_wxp", &KernelOptions::pk_wxp, 25, 400}, {"pk_wz", &KernelOptions::pk_wz, 25, 400},
 };
 }  // namespace
 

@@ -38,7 +38,7 @@ struct KernelOptions {
     int pk_order = 1;     //   1: edge segments first in every phase (the flag goes out early), 0: strip order, the flag goes out at the end of the phase
     int pk_nosync = 0;    //   1: no synchronisation between tiles -- WRONG RESULTS, timing experiments only
     int pk_prio = 1;      //   1: wave priorities dealt so that the two workgroups of a CU interleave (the arbiter serves the oldest wave first)
-    int pk_wx = 150, pk_wz = 100;  //   tiling by cost: a row segment inside the x / z C-PML layers, in percent of a plain one
+    int pk_wx = 150, pk_wxp = 150, pk_wz = 115;  //   tiling by cost: a row segment across the edge of / wholly inside the x C-PML layers, a row inside the z layers, in percent of a plain one
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an
                           // opt-in quadrature of the same time integral, exact for wavefields sampled above twice their bandwidth)
 };

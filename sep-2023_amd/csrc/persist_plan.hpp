@@ -39,14 +39,15 @@ struct PersistPlan {
 // Builds the plan; returns an empty string, or why the grid cannot be tiled this way (e.g. a tile with more than kPlanMaxNb
 // neighbours).  Rows [0, nzc) x segment columns [0, nseg).  edge_first = false keeps the strip order inside a tile (better cache locality) and
 // lets n_edge = n_seg: such a tile publishes a phase only when it is through with all of it.
-// Cost weights (optional): a row segment that contains cells of the x C-PML layers (columns x < npml or x > nx - npml - 1) counts
-// w_xpml percent of a plain one, rows inside the z layers w_zpml percent, band b's rows band_w[b] percent (null: 100): the sequence
+// Cost weights (optional): a row segment that straddles the edge of an x C-PML layer (columns x < npml or x > nx - npml - 1: its
+// waves run the reverse-time bodies AND the absorbing-layer branches of the adjoint ones) counts w_xpml percent of a plain one, a
+// segment wholly inside a layer w_xpure percent, rows inside the z layers w_zpml percent, band b's rows band_w[b] percent (null: 100): the sequence
 // is cut into runs of equal COST, so the tiles that own the absorbing strips get fewer segments (they execute the C-PML branches:
 // about twice the loads) and every tile takes the same time per phase -- tiles wait for their neighbours every phase, the slowest
 // one sets the pace of all (profiles/r05_pk_trace.txt).
 struct PlanCost {
     int nx = 0, npml = 0;            // grid width in cells, layer thickness; nx = 0: no weighting
-    int w_xpml = 100, w_zpml = 100;  // percent
+    int w_xpml = 100, w_xpure = 100, w_zpml = 100;  // percent
     const int *band_w = nullptr;     // [nband] percent, or null
 };
 std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true,

@@ -347,7 +347,7 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
     if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
     Persist &k = pk_;
-    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx && k.wz == opt.pk_wz && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
+    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
         if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
         return k.state == 1;
     }
@@ -367,10 +367,12 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     cost.nx = g_.nx;
     cost.npml = g_.nPml;
     cost.w_xpml = opt.pk_wx;
+    cost.w_xpure = opt.pk_wxp;
     cost.w_zpml = opt.pk_wz;
     k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
     k.order = opt.pk_order;
     k.wx = opt.pk_wx;
+    k.wxp = opt.pk_wxp;
     k.wz = opt.pk_wz;
     if (!k.why.empty()) return false;
     // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a in that order; b stays in HBM)

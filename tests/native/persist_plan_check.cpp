@@ -57,7 +57,8 @@ static int check(int nzc, int nseg, int nwg, int nband, int sw, const PlanCost *
         long long w = 100;
         if (cost && cost->nx > 0) {
             const int x0 = xs * 64, x1 = std::min(cost->nx, x0 + 64) - 1;
-            if (x0 < cost->npml || x1 > cost->nx - cost->npml - 1) w = w * cost->w_xpml / 100;
+            const int in_layers = std::max(0, std::min(x1, cost->npml - 1) - x0 + 1) + std::max(0, x1 - std::max(x0, cost->nx - cost->npml) + 1);
+            if (in_layers > 0) w = w * (in_layers == x1 - x0 + 1 ? cost->w_xpure : cost->w_xpml) / 100;
             if (z < cost->npml || z > nzc - cost->npml - 1) w = w * cost->w_zpml / 100;
         }
         return std::max(1LL, w);
@@ -100,6 +101,7 @@ int main(int argc, char **argv) {
             pc.npml = (int)(rng() % 70);
             pc.w_xpml = 25 + (int)(rng() % 300);
             pc.w_zpml = 25 + (int)(rng() % 300);
+            pc.w_xpure = 25 + (int)(rng() % 300);
             for (int b = 0; b < 8; b++) bw[b] = 60 + (int)(rng() % 100);
             pc.band_w = (rng() % 2) ? bw : nullptr;
         }
