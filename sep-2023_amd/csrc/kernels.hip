@@ -34,6 +34,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd_b_batch(Grid g, const ShotDev *__r
 #ifdef SEPFWI_PK_TRACE
 // one-off wave timeline of the loop (build with SEPFWI_HIPCC_FLAGS=-DSEPFWI_PK_TRACE; scripts/gpu_r05_pk_trace.sh, scripts/pk_trace.py):
 // per (tile, wave, phase 200..207 of the launch) s_memrealtime at the phase start (after the barrier), at each item start (up to 8), at
-// the end of the wave's items and after the closing drain.  Written to pinned host memory, dumped to $SEPFWI_PK_TRACE at exit.
+// the end of the wave's items and after the closing drain.  Kept in device memory, dumped to $SEPFWI_PK_TRACE at exit.
 __device__ unsigned long long *g_pk_trace;
 constexpr int kTrTiles = 512, kTrPh0 = 200, kTrPh = 8, kTrSlots = 12;
 #endif
@@ -1652,16 +1653,18 @@ int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, c
     if (!k) return -1;
 #ifdef SEPFWI_PK_TRACE
     {
-        static unsigned long long *h_tr = nullptr;
+        static unsigned long long *d_tr = nullptr;
         static size_t tr_n = (size_t)kTrTiles * 16 * kTrPh * kTrSlots;
-        if (!h_tr && getenv("SEPFWI_PK_TRACE")) {
-            (void)hipHostMalloc((void **)&h_tr, tr_n * sizeof(unsigned long long), hipHostMallocDefault);
-            memset(h_tr, 0, tr_n * sizeof(unsigned long long));
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pk_trace), &h_tr, sizeof(h_tr));
+        if (!d_tr && getenv("SEPFWI_PK_TRACE")) {
+            (void)hipMalloc((void **)&d_tr, tr_n * sizeof(unsigned long long));
+            (void)hipMemset(d_tr, 0, tr_n * sizeof(unsigned long long));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pk_trace), &d_tr, sizeof(d_tr));
             atexit([] {
+                std::vector<unsigned long long> h(tr_n);
                 (void)hipDeviceSynchronize();
+                (void)hipMemcpy(h.data(), d_tr, tr_n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                 if (FILE *fp = fopen(getenv("SEPFWI_PK_TRACE"), "wb")) {
-                    fwrite(h_tr, sizeof(unsigned long long), tr_n, fp);
+                    fwrite(h.data(), sizeof(unsigned long long), tr_n, fp);
                     fclose(fp);
                 }
             });
