@@ -18,13 +18,13 @@
 
 namespace sepfwi {
 
-constexpr int kPlanMaxNb = 16;
+constexpr int kPlanMaxNb = 28;
 constexpr uint32_t kSegEdge = 1u << 24, kSegXband = 1u << 25;
 
 struct TileHdr {  // device-readable
     int n_edge, n_seg, n_nb;
     int nb[kPlanMaxNb];  // tiles this tile exchanges halos with
-    int pad[13];         // 128 bytes: one header per cache line
+    int pad[1];          // 128 bytes: one header per cache line
 };
 static_assert(sizeof(TileHdr) == 128, "TileHdr is one 128-byte line");
 

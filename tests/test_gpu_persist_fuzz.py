@@ -1,5 +1,5 @@
 """Seeded random geometries for the persistent backward loop (-m gpu): grid size and aspect, layer width, bottom padding, record
-length, shot positions, strip width of the tiling, LDS mask, imaging interval and the order of a tile's segments are drawn per case; the
+length, shot positions, strip width and cost weights of the tiling, wave-priority scheme, LDS mask, imaging interval and the order of a tile's segments are drawn per case; the
 loop must give the two-launch step's misfit, gradients and source gradients BIT FOR BIT (same bodies, same order of operations on
 every array) -- which makes any stale halo read, any missed hand-off between tiles, visible.  No oracle involved: seconds per draw.
 One-off sweeps: SEPFWI_PFUZZ_N=200 (profiles/r05_persist_fuzz.txt)."""
@@ -37,7 +37,10 @@ def test_persistent_loop_random_geometry_is_bit_identical(tmp_path, hip_ops, see
     lam = (lam * 1.05).contiguous()
     common = dict(batch=0, img_every=int(rng.choice([1, 1, 1, 2, 3])), early=int(rng.choice([0, 0, 3])))
     loop = dict(pk_px=int(rng.integers(1, 9)), pk_lmask=int(rng.choice([16, 16, 15, 7, 3, 1, 0])), pk_order=int(rng.integers(0, 2)),
-                pk_wpc=int(rng.choice([2, 2, 2, 1])))
+                pk_wpc=int(rng.choice([2, 2, 2, 1])), pk_prio=int(rng.integers(0, 4)),
+                # tiling by cost: weights of the absorbing strips from 0.7 to three times a plain segment (lighter strips would give their
+                # tiles more segments than the explicit LDS masks drawn above can hold)
+                pk_wx=int(rng.choice([150, 100, 70, 300])), pk_wxp=int(rng.choice([150, 100, 70, 250])), pk_wz=int(rng.choice([115, 100, 70, 220])))
     with P.kernel_options(bwd_fuse=2, **common):
         ref = [t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])]
     with P.kernel_options(bwd_fuse=4, **common, **loop):
