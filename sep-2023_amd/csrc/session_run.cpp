@@ -347,13 +347,14 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
     if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
     Persist &k = pk_;
-    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && (opt.pk_lmask == 16 || k.lmask == opt.pk_lmask)) {
+    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask) {
         if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
         return k.state == 1;
     }
     k.state = 0;
     k.wpc = opt.pk_wpc;
     k.strip_w = opt.pk_px;
+    k.lmask_req = opt.pk_lmask;
     int ncu = 0;
     HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, gpu_id_));
     const int nband = 8, nseg = (g_.nx + 63) / 64;
