@@ -211,7 +211,8 @@ def kernel_source_digest():
     counters were collected on (scripts/make_traffic_json.py)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "device_common.hpp", "fwi_types.hpp"):
+    for f in ("kernels.hip", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp",
+              "device_common.hpp", "fwi_types.hpp"):
         with open(os.path.join(ROOT, "sep-2023_amd", "csrc", f), "rb") as fp:
             h.update(fp.read())
     return h.hexdigest()

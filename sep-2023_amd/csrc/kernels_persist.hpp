@@ -1,0 +1,260 @@
+// kernels_persist.hpp -- k_bwd_persist, the persistent backward time loop
+// Part of the ONE translation unit kernels.hip (included there, inside namespace sepfwi): the kernels share their bodies as
+// inline functions, and every kernel structure must compile them identically (bit-identical results).
+
+// ---------------------------------------------------------------------------------------------
+// Persistent backward time loop (option bwd_fuse = 4): ONE launch advances a shot through a whole backward
+// pass.  The grid is occupancy-sized (every workgroup resident at once); a workgroup owns a fixed tile of 64-column row
+// segments (host-built plan, persist_plan.hpp: every tile the same size +- 1, edge segments first) and walks it twice per
+// time step: phase A = the k_bwd_a bodies, phase B = the k_bwd_b bodies -- the same bodies, the same order of operations on
+// every array (Src/libCUFD.cu:545-631), hence bit-identical results.  What fixed ownership buys: the tile's imaging
+// accumulators stay in LDS (template mask LMASK) instead of 8 B of HBM read-modify-write each per cell and step, and there is
+// no grid fill / drain between the 2 x 3999 phases of a pass.
+//
+// Synchronisation between tiles (phases are numbered through the pass; flags[tile] = phases whose EDGE part is complete):
+//   * a stencil reaches at most two rows / one segment column into a neighbouring tile, and everything a phase reads through
+//     a stencil was written in the previous phase -- so a tile may start phase p once every neighbour has finished the edge
+//     part of phase p-1 (their new values are there: RAW; they have read my old ones: WAR).  Edge segments come first in a
+//     phase, the flag is published when the last wave has seen its edge stores acknowledged, and the interior part hides the
+//     latency: the poll at the next phase start normally succeeds at once.  A workgroup barrier per phase orders the tile's own
+//     waves.
+//   * visibility: band = blockIdx % nband is the XCD (checked at run time: all workgroups of a band must report one XCC_ID),
+//     so tiles that exchange halos share an L2 except across the nband - 1 band edges.  Inside a band plain stores are in the
+//     shared L2 once acknowledged; the reader drops its CU's vector L1 once per phase (agent-scope acquire) after the poll.
+//     Segments next to another band (kSegXband) run the bodies with MemAgent: sc1 loads and write-through stores.
+//   * the pass starts with a rendezvous of the whole grid (below): if the grid is not resident at once, or a band is spread over
+//     several XCDs, every workgroup leaves before anything is touched and the host runs the two-launch step instead.
+//   * every spin is bounded; a time-out later in the pass raises *err, every workgroup leaves, the host reports it.
+// Two things the wave timeline showed (profiles/r05_pk_trace.txt): tiles wait for their neighbours every phase, so the slowest tile
+// sets the pace of all --
+//   * the instruction arbiter serves the OLDEST wave first, and in a launch that never ends the CU's first workgroup stays the older
+//     one: its tile ran a third faster than the second workgroup's (17 against 26 us per phase).  Wave priorities (s_setprio) are
+//     therefore dealt so that the two workgroups interleave -- each has half of its waves on the upper pair of levels, and which
+//     workgroup gets the odd levels alternates from phase to phase (option pk_prio);
+//   * tiles that own the x C-PML strips execute the absorbing-layer branches (twice the loads): the host-built tiling cuts by cost,
+//     not by count (persist_plan.hpp PlanCost, options pk_wx / pk_wz).
+// Segment descriptors are read through the scalar cache: a vector load of one waits with vmcnt(0), i.e. for the previous row segment's
+// stores as well (2.6 % of the backward step).
+// ---------------------------------------------------------------------------------------------
+#ifdef SEPFWI_PK_TRACE
+// one-off wave timeline of the loop (build with SEPFWI_HIPCC_FLAGS=-DSEPFWI_PK_TRACE; scripts/gpu_r05_pk_trace.sh, scripts/pk_trace.py):
+// per (tile, wave, phase 200..207 of the launch) s_memrealtime at the phase start (after the barrier), at each item start (up to 8), at
+// the end of the wave's items and after the closing drain.  Kept in device memory, dumped to $SEPFWI_PK_TRACE at exit.
+__device__ unsigned long long *g_pk_trace;
+constexpr int kTrTiles = 512, kTrPh0 = 200, kTrPh = 8, kTrSlots = 12;
+#endif
+constexpr int kPersistSpinLimit = 1 << 21;   // polls of ~1 us: about two seconds (never reached once the start rendezvous has passed)
+constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
+
+// registers sized for 8 waves per SIMD: two workgroups of 16 waves per CU
+template <int LMASK>
+__global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
+    extern __shared__ float lds_dyn[];
+    __shared__ int next_item, edge_done, abort_flag, start_verdict, cu_slot_s;
+    const ShotDev &s = a.s;
+    const size_t n = a.n;
+    const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
+    const PmlMem m = mem_of(s.bmem, n);
+    const Media md = media_of(a.media, n);
+    const PmlCoef pc = coef_of(a.cz, a.cz + 6 * g.nzc, g.nzc, g.nx);
+    const int band = (int)(blockIdx.x % a.nband);
+    const int tile = band * a.per_band + (int)(blockIdx.x / a.nband);
+    const TileHdr &h = a.hdr[tile];
+    typedef const uint32_t __attribute__((address_space(4))) *seg_table_t;  // constant for the launch: scalar loads
+    const seg_table_t segs = (seg_table_t)(a.seg + (size_t)tile * (size_t)a.cap);
+    const int nst = h.n_seg, n_edge = h.n_edge, nnb = h.n_nb;
+    const int lane = threadIdx.x & (BX - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    lds_float *const lbase = (lds_float *)lds_dyn;
+    AccT<LMASK> acc{acc_of(s.acc, n), nullptr, a.cap * BX};
+    unsigned int *const my_flag = a.flags + (size_t)tile * 32;
+
+    // ---- start rendezvous: nothing is touched before EVERY workgroup of the grid is known to be resident (they wait for each
+    // other all pass long and cannot be pre-empted) and every band is known to sit on one XCD.  ONE word decides for all:
+    // the last arriver votes GO, a workgroup that has waited too long (the GPU is busy with something else: another process'
+    // kernels, another persistent grid) votes ABORT; whichever compare-and-swap comes first stands, also for late arrivers.
+    if (threadIdx.x == 0) {
+        next_item = 0;
+        edge_done = 0;
+        abort_flag = 0;
+        unsigned int verdict = kPersistGo;
+        if (a.nosync && blockIdx.x == 0) atomicExch(a.band_xcc + 9, kPersistGo);  // (the host reads the decision word)
+        if (!a.nosync) {
+            unsigned int *arrived = a.band_xcc + 8, *decision = a.band_xcc + 9;
+            const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID, 4 bits
+            const unsigned int seen = atomicCAS(a.band_xcc + band, 0xffffffffu, xcc);  // first comer records, the others compare
+            if (seen != 0xffffffffu && seen != xcc) atomicCAS(decision, 0u, kPersistAbortPlacement);
+            if (atomicAdd(arrived, 1u) == gridDim.x - 1) atomicCAS(decision, 0u, kPersistGo);
+            int spins = 0;
+            while ((verdict = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kPersistStartLimit) atomicCAS(decision, 0u, kPersistAbortResidency);
+            }
+        }
+        start_verdict = (int)verdict;
+        // first or second workgroup on this CU?  (arrival order at a per-CU counter kept in the spare words of the flag lines)
+        const unsigned int hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_REG_HW_ID: bits 8..15 = CU, shader array, engine
+        const unsigned int xcc_ = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID
+        const unsigned int key = (xcc_ << 8) | ((hwid >> 8) & 0xffu);
+        cu_slot_s = (int)atomicAdd(a.flags + (size_t)(key % gridDim.x) * 32 + 1 + (key / gridDim.x) % 31, 1u);
+    }
+    __syncthreads();  // (all waves keep their registers meanwhile: a workgroup reduced to one wave would make room for one that does not fit)
+    if (start_verdict != (int)kPersistGo) return;
+    const int cu_slot = cu_slot_s;
+    auto set_prio = [&](int p) {  // (the instruction takes an immediate)
+        switch (p & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
+    auto cell_of = [&](uint32_t d) {
+        Cell c;
+        c.z = __builtin_amdgcn_readfirstlane((int)(d & 0xffffu));
+        c.x = (int)((d >> 16) & 0xffu) * BX + lane;
+        c.i = (size_t)c.z * (size_t)g.pitch + (size_t)c.x;
+        return c;
+    };
+    // prologue: the tile's accumulators HBM -> LDS (they carry the sum over the shots of the call)
+    if constexpr (LMASK != 0) {
+        for (int j = wave; j < nst; j += nw) {
+            const Cell c = cell_of(segs[j]);
+            lds_float *cell = lbase + j * BX + lane;
+            int r = 0;
+            if constexpr (LMASK & 1) cell[(r++) * acc.stride] = acc.p.lam[c.i];
+            if constexpr (LMASK & 2) cell[(r++) * acc.stride] = acc.p.mu[c.i];
+            if constexpr (LMASK & 4) cell[(r++) * acc.stride] = acc.p.xz[c.i];
+            if constexpr (LMASK & 8) cell[(r++) * acc.stride] = acc.p.a[c.i];
+        }
+    }
+    __syncthreads();
+
+    auto grab = [&]() {  // next work item of the workgroup: (phase, segment) in execution order
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&next_item, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    int w = grab();
+    int local = 0;  // phases done in this launch; a.phase0 + local numbers them through the pass
+    bool dead = abort_flag != 0;
+    for (int it = a.it_hi; it >= a.it_lo && !dead; it--) {
+        Grid gs = g;
+        if (a.img_every > 1) gs.dt_img = (it % a.img_every == 0) ? (float)a.img_every * g.dt : 0.0f;
+        float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
+        const float amp = __fmul_rn(__fmul_rn(a.src_scale, s.stf[it]), g.dt);
+        const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
+        for (int ph = 0; ph < 2 && !dead; ph++, local++) {
+            const unsigned int phase = (unsigned int)(a.phase0 + local);
+            // ---- neighbours through the edge part of the previous phase?  then drop what this CU's L1 still holds of their rows
+            if (wave == 0 && !a.nosync) {
+                bool ok = true;
+                if (phase > 0 && lane < nnb) {
+                    const unsigned int *pf = a.flags + (size_t)h.nb[lane] * 32;
+                    int spins = 0;
+                    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > kPersistSpinLimit ||
+                            ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                }
+                if (!__all(ok)) {
+                    if (lane == 0) {
+                        atomicCAS(a.err, 0, 1);
+                        abort_flag = 1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();  // the tile's own waves: everything of the previous phase is stored; poll and invalidate are done
+            if (abort_flag) {
+                dead = true;
+                break;
+            }
+            const int base = local * nst;
+            bool reported = false;
+            // waves w, w+4, w+8, w+12 of a workgroup share a SIMD: two of them on levels {2, 3}, two on {0, 1}; the odd levels go to
+            // the CU's first workgroup in even phases and to the second in odd ones
+            if (a.prio == 1) set_prio(2 * ((wave >> 2) & 1) + ((cu_slot ^ local) & 1));
+            else if (a.prio == 2) set_prio(2 * ((wave >> 2) & 1) + (cu_slot & 1));
+            else if (a.prio == 3) set_prio(2 * ((wave >> 2) & 1) + ((cu_slot ^ (local % 3 == 0)) & 1));
+#ifdef SEPFWI_PK_TRACE
+            unsigned long long *tr = nullptr;
+            int tr_k = 1;
+            if (g_pk_trace && tile < kTrTiles && wave < 16 && local >= kTrPh0 && local < kTrPh0 + kTrPh && a.phase0 == 0)
+                tr = g_pk_trace + (((size_t)tile * 16 + wave) * kTrPh + (local - kTrPh0)) * kTrSlots;
+            if (tr && lane == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+            // a wave that has seen its last edge segment of the phase waits for its stores, counts itself in; the last one publishes
+            auto report = [&]() {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (lane == 0) old = atomicAdd(&edge_done, 1);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old + 1 == nw * (local + 1) && lane == 0 && !a.nosync)
+                    __hip_atomic_store(my_flag, phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                reported = true;
+            };
+            for (; w < base + nst; w = grab()) {
+                const int j = w - base;
+#ifdef SEPFWI_PK_TRACE
+                if (tr && lane == 0 && tr_k < 9) tr[tr_k++] = __builtin_amdgcn_s_memrealtime();
+#endif
+                if (j >= n_edge && !reported) report();
+                const uint32_t d = segs[j];
+                const Cell c = cell_of(d);
+                acc.cell = lbase + j * BX + lane;
+                const bool xband = (d & kSegXband) != 0 && !a.nosync;  // wave-uniform
+                if (ph == 0) {
+                    // phase A: reverse-time velocity (+ rho imaging, frame restore) + adjoint stress of the previous step
+                    if (xband) {
+                        velocity_body<false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+                        stress_adj_body<MemAgent>(gs, c, adj, m, md, pc);
+                    } else {
+                        velocity_body<false>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+                        stress_adj_body(gs, c, adj, m, md, pc);
+                    }
+                } else {
+                    // phase B: source_grad + reverse-time stress (+ lambda/mu imaging, frame restore) + adjoint velocity + injection
+                    if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
+                    if (xband) {
+                        stress_body<false, false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+                        velocity_adj_body<MemAgent>(gs, c, adj, m, md, pc, lr);
+                    } else {
+                        stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+                        velocity_adj_body(gs, c, adj, m, md, pc, lr);
+                    }
+                }
+            }
+#ifdef SEPFWI_PK_TRACE
+            if (tr && lane == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (!reported) report();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the phase are complete before the next barrier
+#ifdef SEPFWI_PK_TRACE
+            if (tr && lane == 0) {
+                tr[10] = __builtin_amdgcn_s_memrealtime();
+                tr[11] = (unsigned long long)tr_k;
+            }
+#endif
+        }
+    }
+    __syncthreads();
+
+    // epilogue: LDS -> HBM
+    if constexpr (LMASK != 0) {
+        for (int j = wave; j < nst; j += nw) {
+            const Cell c = cell_of(segs[j]);
+            lds_float *cell = lbase + j * BX + lane;
+            int r = 0;
+            if constexpr (LMASK & 1) acc.p.lam[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 2) acc.p.mu[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 4) acc.p.xz[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 8) acc.p.a[c.i] = cell[(r++) * acc.stride];
+        }
+    }
+}

@@ -13,7 +13,7 @@ _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
 SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "config.cpp", "capi.cpp"]
-HEADERS = ["kernels.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+HEADERS = ["kernels.hpp", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
 _lib = None
