@@ -151,7 +151,11 @@ int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
  * gradients within 1e-4 of every-step imaging for the usual wavelets; NOT covered by the next sentence), obs_cache_mb 0,
  * quiet_skip 0 (1: updates of 64-cell row segments whose every input is exactly +0 -- the fields ahead of the wave front -- are left
  * out; bit-identical results; shots whose channels are a line, forward kernels and the two-launch backward step),
- * quiet_rows 4 (rows per wave of the forward kernels while quiet_skip is on).
+ * quiet_rows 4 (rows per wave of the forward kernels while quiet_skip is on); the persistent backward loop: pk_lmask 16
+ * (imaging accumulators kept in LDS; 16: as many as fit), pk_wpc 2 / pk_waves 16 (workgroups per CU, waves each), pk_px 3 (strip width
+ * of the tiling), pk_order 1 (edge segments first), pk_prio 1 (wave priorities interleave the CU's two workgroups), pk_wx 150 / pk_wxp 150
+ * / pk_wz 115 (tiling by cost: percent of a plain row segment for one across the edge of / wholly inside the x C-PML layers, for a row
+ * inside the z layers), pk_nosync 0 (1: timing experiments only, WRONG results).
  * sepfwi_set_option edits the process-wide defaults under a lock; every sepfwi_cufd* call takes ONE snapshot of them when
  * it starts, so a call never sees a half-changed block and concurrent calls on other GPUs are unaffected.  Results are
  * identical (to the parity tolerances) for every setting.  Returns SEPFWI_EINVAL for unknown names or values;
