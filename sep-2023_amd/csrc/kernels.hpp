@@ -21,7 +21,7 @@ struct KernelOptions {
     int amu_fly = 1;      // harmonic mean of mu rebuilt from mu: bit 0 forward stress kernel (+3.8 %), bit 1 backward kernels (-1 %)
     int rk_lazy = 1;      // adjoint kernels load 1/K only inside the C-PML layers (it is exactly 1 elsewhere)
     int batch = 2;        // shots of a call advance in batched launches: 0 never (one stream per forward lane), 1 always,
-                          // 2 when at least two backward passes fit the cache budget together
+                          // 2 when at least three backward passes fit the cache budget together (two with the two-launch backward step)
     int batch_f = 0, batch_b = 0;  // explicit forward / backward batch sizes (0: from batch_mb)
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)

@@ -749,12 +749,15 @@ void Session::run(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad
     obs_->release_all();
 
     // Batch sizes from the Infinity-Cache budget: a forward batch keeps 5 fields per shot + 5 media arrays resident, a backward
-    // batch 15 arrays per shot + 5 (2000x500: 7 and 2; a 101x201 notebook problem: all its shots at once).  Where not even two
-    // backward passes fit (2000x1000) the stream schedule runs the backward passes one by one.
+    // batch 15 arrays per shot + 5 (2000x500: 7 and 2; a 101x201 notebook problem: all its shots at once).  Where fewer than three
+    // backward passes fit (two-launch step: two) the stream schedule runs them one by one -- as the persistent loop where it is
+    // eligible: measured fwd+adj at 1000 steps, batched / streams in Gcell-updates/s: 2000x500 (2 fit) 73.5 / 79.6, 1500x500 (3) 77.1 /
+    // 75.0, 1000x700 (3) 73.2 / 72.5, 2000x300 (4) 73.7 / 66.1, 1000x500 (5) 69.0 / 63.9 (profiles/r05_other_grids.txt).
     const double arr_mb = (double)cells_ * sizeof(float) / 1.0e6, budget = (double)c.opt.batch_mb;
     int Bf = (int)((budget / arr_mb - 5.0) / 5.0), Bb = (int)((budget / arr_mb - 5.0) / 15.0);
+    const int bb_min = c.opt.bwd_fuse == 4 ? 3 : 2;
     const bool batched = c.opt.bwd_fuse != 0 && group_size >= 1 &&
-                         (c.opt.batch == 1 || (c.opt.batch == 2 && (c.with_adj ? Bb >= 2 : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
+                         (c.opt.batch == 1 || (c.opt.batch == 2 && (c.with_adj ? Bb >= bb_min : Bf >= 8)));  // forward-only calls: streams until kernels are launch-bound
     last_batched_ = batched;
     if (batched) {
         if (c.opt.batch_f > 0) Bf = c.opt.batch_f;
