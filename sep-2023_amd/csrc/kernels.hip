@@ -82,7 +82,7 @@ const OptField kOptFields[] = {
     {"amu_fly", &KernelOptions::amu_fly, 0, 3},   {"rk_lazy", &KernelOptions::rk_lazy, 0, 1},
     {"batch", &KernelOptions::batch, 0, 2},       {"batch_f", &KernelOptions::batch_f, 0, 64},
     {"batch_b", &KernelOptions::batch_b, 0, 64},  {"batch_mb", &KernelOptions::batch_mb, 1, 1 << 20},
-    {"batch_order", &KernelOptions::batch_order, 0, 1},
+    {"batch_order", &KernelOptions::batch_order, 0, 1}, {"batch_split", &KernelOptions::batch_split, 1, 3},
     {"probe", &KernelOptions::probe, 0, 1 << 30},
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},

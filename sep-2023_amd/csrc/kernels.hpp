@@ -25,6 +25,8 @@ struct KernelOptions {
     int batch_f = 0, batch_b = 0;  // explicit forward / backward batch sizes (0: from batch_mb)
     int batch_mb = 200;   // Infinity-Cache budget [MB] that sizes a batch: (5 B + 5) arrays forward, (15 B + 5) backward
     int batch_order = 1;  // batched launches: 0 shot-major block order, 1 the shots of one tile back to back (L2 reuse of the media)
+    int batch_split = 2;  // batched launches: a batch as this many sub-batches on streams of their own (1..3): launches of different queues
+                          // overlap their fill and drain (+5 % at 1000x500, +16 % on a 100x200 notebook-sized problem with 19 shots)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
     int quiet_skip = 0;   // 1: updates of row segments whose every input is exactly +0 are left out (the fields ahead of the wave front; same bits).
                           // Used by the forward kernels and the two-launch backward step; line receivers (or none) only

@@ -623,12 +623,36 @@ void Session::run_batched(Call &c, int Bf, int Bb) {
         // ---- forward time loop, libCUFD.cu:268-332
         HIP_OK(hipEventRecord(ev_[0], st));
         for (int k = 0; k < nb; k++) forward_init(cx[k]);
+        // the batch as up to three sub-batches on streams of their own (option batch_split): launches of different queues overlap
+        int ns = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nb));
+        for (int k = 0; k < nb; k++)
+            if (!(tab[is0 + k].comps & 16)) ns = 1;  // (general receivers are sampled by launches on the call's stream)
+        hipStream_t sub[kMaxLanes] = {st, nullptr, nullptr, nullptr};
+        if (ns > 1) {
+            for (int q = 1; q < ns; q++) {
+                XLane &L = xl_[q];
+                if (!L.stream) {
+                    HIP_OK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+                    HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
+                }
+                sub[q] = L.stream;
+            }
+            HIP_OK(hipEventRecord(ev_order_, st));
+            for (int q = 1; q < ns; q++) HIP_OK(hipStreamWaitEvent(sub[q], ev_order_, 0));
+        }
         for (int it = 0; it <= nSteps - 2; it++) {
-            launch_stress_fwd_batch(st, g, opt, d_shots_ + is0, nb, md_, pc_, n, data_len_, it, c.src_scale, c.with_adj);
-            launch_velocity_fwd_batch(st, g, opt, d_shots_ + is0, nb, md_, pc_, n);
-            launches_ += 2;
+            for (int q = 0; q < ns; q++) {
+                const int a0 = (int)((long long)nb * q / ns), a1 = (int)((long long)nb * (q + 1) / ns);
+                launch_stress_fwd_batch(sub[q], g, opt, d_shots_ + is0 + a0, a1 - a0, md_, pc_, n, data_len_, it, c.src_scale, c.with_adj);
+                launch_velocity_fwd_batch(sub[q], g, opt, d_shots_ + is0 + a0, a1 - a0, md_, pc_, n);
+                launches_ += 2;
+            }
             for (int k = 0; k < nb; k++)
                 if (!(tab[is0 + k].comps & 16)) record_column(cx[k], it + 1);  // general receivers: sample the new state into column it+1
+        }
+        for (int q = 1; q < ns; q++) {
+            HIP_OK(hipEventRecord(xl_[q].join, sub[q]));
+            HIP_OK(hipStreamWaitEvent(st, xl_[q].join, 0));
         }
         for (int k = 0; k < nb; k++)
             if (tab[is0 + k].comps & 16) record_column(cx[k], nSteps - 1);
@@ -651,13 +675,32 @@ void Session::run_batched(Call &c, int Bf, int Bb) {
             for (int k = 0; k < nbb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd, 0, 13 * n * sizeof(float), st));  // memories + adjoint fields
             for (int k = 0; k < nbb; k++)
                 if (cx[kb + k].quiet) HIP_OK(hipMemsetAsync(cx[kb + k].quiet + 2 * (size_t)g.qn, 0, 2 * (size_t)g.qn * sizeof(unsigned int), st));
+            int nsb = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nbb));  // sub-batches on streams of their own, as in the forward loop
+            for (int k = 0; k < nbb; k++)
+                if (tab[is0 + kb + k].lr_n == 0) nsb = 1;  // (k_inject runs on the call's stream)
+            if (nsb > 1) {
+                for (int q = 1; q < nsb; q++) {
+                    XLane &L = xl_[q];
+                    if (!L.stream) {
+                        HIP_OK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+                        HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
+                    }
+                    sub[q] = L.stream;
+                }
+                HIP_OK(hipEventRecord(ev_order_, st));
+                for (int q = 1; q < nsb; q++) HIP_OK(hipStreamWaitEvent(sub[q], ev_order_, 0));
+            }
             for (int it = nSteps - 2; it >= 0; it--) {
                 hipEvent_t *ev = probe_pair(c, it);
                 Grid gs = g;
                 if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-                launch_bwd_a_batch(st, gs, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it);
-                launch_bwd_b_batch(st, gs, opt, d_shots_ + is0 + kb, nbb, md_, pc_, n, it, c.src_scale, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-                launches_ += 2;
+                for (int q = 0; q < nsb; q++) {
+                    const int a0 = (int)((long long)nbb * q / nsb), a1 = (int)((long long)nbb * (q + 1) / nsb);
+                    launch_bwd_a_batch(sub[q], gs, opt, d_shots_ + is0 + kb + a0, a1 - a0, md_, pc_, n, it);
+                    launch_bwd_b_batch(sub[q], gs, opt, d_shots_ + is0 + kb + a0, a1 - a0, md_, pc_, n, it, c.src_scale, (ev && q == 0) ? ev[0] : nullptr,
+                                       (ev && q == 0) ? ev[1] : nullptr);
+                    launches_ += 2;
+                }
                 for (int k = 0; k < nbb; k++)
                     if (tab[is0 + kb + k].lr_n == 0) {
                         const ShotCtx &x = cx[kb + k];
@@ -665,6 +708,10 @@ void Session::run_batched(Call &c, int Bf, int Bb) {
                         launch_inject(st, g, adj, x.nrec, x.rec, x.res + (size_t)it * x.nrec, x.sens);
                         launches_++;
                     }
+            }
+            for (int q = 1; q < nsb; q++) {
+                HIP_OK(hipEventRecord(xl_[q].join, sub[q]));
+                HIP_OK(hipStreamWaitEvent(st, xl_[q].join, 0));
             }
             HIP_OK(hipEventRecord(ev_[3], st));
             bwd_steps_ += (long long)nbb * (nSteps - 1);
