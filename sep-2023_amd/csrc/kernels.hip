@@ -87,7 +87,7 @@ const OptField kOptFields[] = {
     {"img_every", &KernelOptions::img_every, 1, 64},
     {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
     {"quiet_skip", &KernelOptions::quiet_skip, 0, 1}, {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
-    {"pk_lmask", &KernelOptions::pk_lmask, 0, 16},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
+    {"pk_lmask", &KernelOptions::pk_lmask, 0, 31},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
     {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
     {"pk_prio", &KernelOptions::pk_prio, 0, 3}, {"pk_wx", &KernelOptions::pk_wx, 25, 400}, {"pk_wxp", &KernelOptions::pk_wxp, 25, 400}, {"pk_wz", &KernelOptions::pk_wz, 25, 400},
 };
@@ -225,6 +225,7 @@ static void (*persist_kernel(int lmask))(Grid, const PersistArgs) {
         case 3: return k_bwd_persist<3>;
         case 7: return k_bwd_persist<7>;
         case 15: return k_bwd_persist<15>;
+        case 31: return k_bwd_persist<31>;
         default: return nullptr;
     }
 }

@@ -33,7 +33,7 @@ struct KernelOptions {
     int quiet_rows = 4;   //   rows per wave of the quiet-skipping FORWARD kernels (a quiet wave costs its dispatch whatever it skips)
     int obs_cache_mb = 0; // HBM budget [MB] of the observed-data store (0: unlimited; a parameter-file key of the same name wins)
     // persistent backward time loop (bwd_fuse = 4; kernels.hip k_bwd_persist)
-    int pk_lmask = 16;    //   imaging accumulators kept in LDS: bit 0 lam, 1 mu, 2 xz, 3 a (16: as many as fit, in that order)
+    int pk_lmask = 16;    //   imaging accumulators kept in LDS: 1 lam, 3 + mu, 7 + xz, 15 + a, 31 + b (16: as many as fit, in that order)
     int pk_wpc = 2;       //   workgroups (16 waves each) per CU
     int pk_px = 3;        //   strip width of the tiling in row segments (persist_plan.hpp)
     int pk_waves = 16;    //   waves per workgroup

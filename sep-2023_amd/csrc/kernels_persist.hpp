@@ -126,6 +126,7 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             if constexpr (LMASK & 2) cell[(r++) * acc.stride] = acc.p.mu[c.i];
             if constexpr (LMASK & 4) cell[(r++) * acc.stride] = acc.p.xz[c.i];
             if constexpr (LMASK & 8) cell[(r++) * acc.stride] = acc.p.a[c.i];
+            if constexpr (LMASK & 16) cell[(r++) * acc.stride] = acc.p.b[c.i];
         }
     }
     __syncthreads();
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             if constexpr (LMASK & 2) acc.p.mu[c.i] = cell[(r++) * acc.stride];
             if constexpr (LMASK & 4) acc.p.xz[c.i] = cell[(r++) * acc.stride];
             if constexpr (LMASK & 8) acc.p.a[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 16) acc.p.b[c.i] = cell[(r++) * acc.stride];
         }
     }
 }

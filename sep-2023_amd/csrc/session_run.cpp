@@ -376,9 +376,9 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     k.wxp = opt.pk_wxp;
     k.wz = opt.pk_wz;
     if (!k.why.empty()) return false;
-    // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a in that order; b stays in HBM)
+    // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a, b in that order)
     const size_t lds_cu = 160 * 1024, per_wg = lds_cu / (size_t)opt.pk_wpc - 256;
-    const int masks[5] = {15, 7, 3, 1, 0};
+    const int masks[6] = {31, 15, 7, 3, 1, 0};  // (all five fit where a tile has at most 63 row segments: grids below the headline's size)
     k.lmask = -1;
     for (int mk : masks) {
         if (opt.pk_lmask != 16 && mk != opt.pk_lmask) continue;

@@ -36,7 +36,7 @@ def test_persistent_loop_random_geometry_is_bit_identical(tmp_path, hip_ops, see
     lam, mu, den = pb["lame_init"]
     lam = (lam * 1.05).contiguous()
     common = dict(batch=0, img_every=int(rng.choice([1, 1, 1, 2, 3])), early=int(rng.choice([0, 0, 3])))
-    loop = dict(pk_px=int(rng.integers(1, 9)), pk_lmask=int(rng.choice([16, 16, 15, 7, 3, 1, 0])), pk_order=int(rng.integers(0, 2)),
+    loop = dict(pk_px=int(rng.integers(1, 9)), pk_lmask=int(rng.choice([16, 16, 31, 15, 7, 3, 1, 0])), pk_order=int(rng.integers(0, 2)),
                 pk_wpc=int(rng.choice([2, 2, 2, 1])), pk_prio=int(rng.integers(0, 4)),
                 # tiling by cost: weights of the absorbing strips from 0.7 to three times a plain segment (lighter strips would give their
                 # tiles more segments than the explicit LDS masks drawn above can hold)
