@@ -143,23 +143,16 @@ typedef struct sepfwi_stats {
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 
 /*
- * Kernel / scheduling options for A/B measurements and for the parity tests of every selectable structure.
- * Names and defaults (struct KernelOptions, csrc/kernels.hpp): bz 2, xcd_remap 1, bwd_fuse 4 (0: the reference's four
- * kernels per backward step, 2: two fused launches, 4: the persistent time loop where eligible), line_fuse 1, pair_fwd 1, fwd_lanes 3, early 0, rho_fly 1, amu_fly 1, rk_lazy 1, batch 2
- * (0 streams, 1 batched launches, 2 by grid size), batch_f 0, batch_b 0, batch_mb 200, batch_order 1, probe 0, img_every 1
- * (k > 1: the imaging condition on every k-th backward step with weight k dt -- an opt-in quadrature of the same time integrals,
- * gradients within 1e-4 of every-step imaging for the usual wavelets; NOT covered by the next sentence), obs_cache_mb 0,
- * quiet_skip 0 (1: updates of 64-cell row segments whose every input is exactly +0 -- the fields ahead of the wave front -- are left
- * out; bit-identical results; shots whose channels are a line, forward kernels and the two-launch backward step),
- * quiet_rows 4 (rows per wave of the forward kernels while quiet_skip is on); the persistent backward loop: pk_lmask 16
- * (imaging accumulators kept in LDS; 16: as many as fit), pk_wpc 2 / pk_waves 16 (workgroups per CU, waves each), pk_px 3 (strip width
- * of the tiling), pk_order 1 (edge segments first), pk_prio 1 (wave priorities interleave the CU's two workgroups), pk_wx 150 / pk_wxp 150
- * / pk_wz 115 (tiling by cost: percent of a plain row segment for one across the edge of / wholly inside the x C-PML layers, for a row
- * inside the z layers), pk_nosync 0 (1: timing experiments only, WRONG results).
- * sepfwi_set_option edits the process-wide defaults under a lock; every sepfwi_cufd* call takes ONE snapshot of them when
- * it starts, so a call never sees a half-changed block and concurrent calls on other GPUs are unaffected.  Results are
- * identical (to the parity tolerances) for every setting.  Returns SEPFWI_EINVAL for unknown names or values;
- * sepfwi_get_option returns the current default or -1.
+ * Options (process-wide defaults; every sepfwi_cufd* call takes ONE snapshot of them when it starts).  Names, defaults, meaning:
+ *   bwd_fuse 4    backward step: 0 the reference's four kernels + injection, 2 two fused launches, 4 the persistent time loop (else 2)
+ *   batch 2       shots of a call: 0 one stream per forward lane, 1 batched launches, 2 chosen by grid size
+ *   quiet_skip 0  1: updates of 64-cell row segments whose every input is exactly +0 are left out (bit-identical)
+ *   obs_cache_mb 0  HBM budget of the observed-data store in MB (0: unlimited; the parameter-file key of the same name wins)
+ *   probe 0       > 0: every probe-th backward launch is timed with HIP events (sepfwi_stats.probe_kernel_us)
+ *   img_every 1   k > 1: imaging condition on every k-th backward step with weight k dt -- an opt-in quadrature, gradients within
+ *                 1e-4 of every-step imaging; the ONLY option that changes results beyond round-off of the parity tolerances
+ * Tuning knobs and timing-only switches exist only in a library built with -DSEPFWI_PROBES (csrc/kernels.hip); here they are unknown
+ * names.  Returns SEPFWI_EINVAL for unknown names or values; sepfwi_get_option returns the current default or -1.
  */
 int sepfwi_set_option(const char *name, int value);
 int sepfwi_get_option(const char *name);

@@ -134,7 +134,8 @@ struct PersistArgs {
                              // [9] the start rendezvous' decision (kPersist*)
     int *err;                // 0, 1 a wait inside the pass timed out
     int phase0;              // phases of the pass done by earlier launches
-    int nosync;              // timing experiments only: no waits, no flags, no agent-scope accesses (results wrong)
+    int nosync;              // -DSEPFWI_PROBES builds, timing experiments only: no waits, no flags, no agent-scope accesses (results wrong)
+    int lock;                // -DSEPFWI_PROBES builds, timing experiments only: phases interleaved (option pk_lock)
     int prio;                // 1: wave priorities interleave the CU's two workgroups (kernels.hip)
 };
 

@@ -74,22 +74,35 @@ struct OptField {
     int KernelOptions::*field;
     int lo, hi;
 };
+// The public table: what a user may set.  Nothing here changes results beyond the parity tolerances (img_every is the one documented
+// quadrature, include/sepfwi.h).  Everything else -- tile shapes, wave counts, launch structures kept for A/B measurements and for the
+// bit-identity tests of every selectable structure, and the timing-only switches that give WRONG results -- exists only in a library
+// built with -DSEPFWI_PROBES (libsepfwi_probes.so: sepfwi/_native.py, scripts/ab_bench.py).
 const OptField kOptFields[] = {
+    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 4},
+    {"batch", &KernelOptions::batch, 0, 2},
+    {"img_every", &KernelOptions::img_every, 1, 64},
+    {"quiet_skip", &KernelOptions::quiet_skip, 0, 1},
+    {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
+    {"probe", &KernelOptions::probe, 0, 1 << 30},
+#ifdef SEPFWI_PROBES
     {"bz", &KernelOptions::bz, 1, 16},           {"xcd_remap", &KernelOptions::xcd_remap, 0, 1},
-    {"bwd_fuse", &KernelOptions::bwd_fuse, 0, 4}, {"line_fuse", &KernelOptions::line_fuse, 0, 1},
+    {"line_fuse", &KernelOptions::line_fuse, 0, 1},
     {"pair_fwd", &KernelOptions::pair_fwd, 0, 1}, {"fwd_lanes", &KernelOptions::fwd_lanes, 1, 4},
     {"early", &KernelOptions::early, 0, 3},       {"rho_fly", &KernelOptions::rho_fly, 0, 3},
     {"amu_fly", &KernelOptions::amu_fly, 0, 3},   {"rk_lazy", &KernelOptions::rk_lazy, 0, 1},
-    {"batch", &KernelOptions::batch, 0, 2},       {"batch_f", &KernelOptions::batch_f, 0, 64},
+    {"batch_f", &KernelOptions::batch_f, 0, 64},
     {"batch_b", &KernelOptions::batch_b, 0, 64},  {"batch_mb", &KernelOptions::batch_mb, 1, 1 << 20},
     {"batch_order", &KernelOptions::batch_order, 0, 1}, {"batch_split", &KernelOptions::batch_split, 1, 3},
-    {"probe", &KernelOptions::probe, 0, 1 << 30},
-    {"img_every", &KernelOptions::img_every, 1, 64},
-    {"obs_cache_mb", &KernelOptions::obs_cache_mb, 0, 1 << 30},
-    {"quiet_skip", &KernelOptions::quiet_skip, 0, 1}, {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
+    {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 31},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
-    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},         {"pk_nosync", &KernelOptions::pk_nosync, 0, 1},
+    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},
     {"pk_prio", &KernelOptions::pk_prio, 0, 3}, {"pk_wx", &KernelOptions::pk_wx, 25, 400}, {"pk_wxp", &KernelOptions::pk_wxp, 25, 400}, {"pk_wz", &KernelOptions::pk_wz, 25, 400},
+    // timing experiments only -- WRONG results: no synchronisation between tiles; phases of a time step interleaved (pk_lock: bits 0-7 the
+    // distance D in row segments by which phase B trails phase A, 0x100 alternate walk direction per time step, 0x200 no barrier per step);
+    // pk_snake 0: every strip of the tiling is walked top-down
+    {"pk_nosync", &KernelOptions::pk_nosync, 0, 1}, {"pk_lock", &KernelOptions::pk_lock, 0, 0x3ff}, {"pk_snake", &KernelOptions::pk_snake, 0, 1},
+#endif
 };
 }  // namespace
 

@@ -38,7 +38,9 @@ struct KernelOptions {
     int pk_px = 3;        //   strip width of the tiling in row segments (persist_plan.hpp)
     int pk_waves = 16;    //   waves per workgroup
     int pk_order = 1;     //   1: edge segments first in every phase (the flag goes out early), 0: strip order, the flag goes out at the end of the phase
-    int pk_nosync = 0;    //   1: no synchronisation between tiles -- WRONG RESULTS, timing experiments only
+    int pk_nosync = 0;    //   (-DSEPFWI_PROBES builds only) 1: no synchronisation between tiles -- WRONG RESULTS, timing experiments
+    int pk_lock = 0;      //   (-DSEPFWI_PROBES builds only) > 0: the two phases of a time step interleaved, timing only (kernels_persist.hpp)
+    int pk_snake = 1;     //   (-DSEPFWI_PROBES builds only) 0: every strip of the tiling is walked top-down
     int pk_prio = 1;      //   1: wave priorities dealt so that the two workgroups of a CU interleave (the arbiter serves the oldest wave first)
     int pk_wx = 150, pk_wxp = 150, pk_wz = 115;  //   tiling by cost: a row segment across the edge of / wholly inside the x C-PML layers, a row inside the z layers, in percent of a plain one
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an

@@ -53,6 +53,11 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
     __shared__ int next_item, edge_done, abort_flag, start_verdict, cu_slot_s;
     const ShotDev &s = a.s;
     const size_t n = a.n;
+#ifdef SEPFWI_PROBES
+    const bool nosync = a.nosync != 0;  // timing experiments (WRONG results): only a library built with -DSEPFWI_PROBES has the switch
+#else
+    constexpr bool nosync = false;
+#endif
     const Fields f = fields_of(s.fields, n), adj = fields_of(s.adj, n);
     const PmlMem m = mem_of(s.bmem, n);
     const Media md = media_of(a.media, n);
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
         edge_done = 0;
         abort_flag = 0;
         unsigned int verdict = kPersistGo;
-        if (a.nosync && blockIdx.x == 0) atomicExch(a.band_xcc + 9, kPersistGo);  // (the host reads the decision word)
-        if (!a.nosync) {
+        if (nosync && blockIdx.x == 0) atomicExch(a.band_xcc + 9, kPersistGo);  // (the host reads the decision word)
+        if (!nosync) {
             unsigned int *arrived = a.band_xcc + 8, *decision = a.band_xcc + 9;
             const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;  // HW_REG_XCC_ID, 4 bits
             const unsigned int seen = atomicCAS(a.band_xcc + band, 0xffffffffu, xcc);  // first comer records, the others compare
@@ -145,10 +150,58 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
         float *frame_t = s.frame + (size_t)it * 5 * (size_t)g.frame_len;
         const float amp = __fmul_rn(__fmul_rn(a.src_scale, s.stf[it]), g.dt);
         const LineRec lr{s.lr_z, s.lr_x0, s.lr_n, nullptr, nullptr, nullptr, s.res + (size_t)it * (size_t)s.nrec};
+        // one work item: phase ph of the time step on row segment j of the tile
+        auto run_item = [&](int ph, int j, bool sync) {
+            const uint32_t d = segs[j];
+            const Cell c = cell_of(d);
+            acc.cell = lbase + j * BX + lane;
+            const bool xband = (d & kSegXband) != 0 && sync;  // wave-uniform
+            if (ph == 0) {
+                // phase A: reverse-time velocity (+ rho imaging, frame restore) + adjoint stress of the previous step
+                if (xband) {
+                    velocity_body<false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+                    stress_adj_body<MemAgent>(gs, c, adj, m, md, pc);
+                } else {
+                    velocity_body<false>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
+                    stress_adj_body(gs, c, adj, m, md, pc);
+                }
+            } else {
+                // phase B: source_grad + reverse-time stress (+ lambda/mu imaging, frame restore) + adjoint velocity + injection
+                if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
+                if (xband) {
+                    stress_body<false, false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+                    velocity_adj_body<MemAgent>(gs, c, adj, m, md, pc, lr);
+                } else {
+                    stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
+                    velocity_adj_body(gs, c, adj, m, md, pc, lr);
+                }
+            }
+        };
+#ifdef SEPFWI_PROBES
+        if (a.lock > 0) {
+            // Timing probe (WRONG results: no synchronisation at all; profiles/EXPERIMENTS.md #47): the two phases of the time step
+            // interleaved along the tile's walk order -- item 2k is phase A of segment k, item 2k + 1 phase B of segment k - D -- so that
+            // what phase A stored is read by phase B while it is still in the XCD's L2 (the ceiling of a dataflow form in which a tile's
+            // phase B trails its phase A by the stencil's reach instead of a whole pass over the tile).
+            const int D = a.lock & 0xff, span = 2 * (nst + D), base = (local >> 1) * span;
+            const bool rev = (a.lock & 0x100) != 0 && ((local >> 1) & 1) != 0;  // every other time step walks the tile backwards
+            for (; w < base + span; w = grab()) {
+                const int mm = w - base, ph = mm & 1;
+                int j = (mm >> 1) - (ph ? D : 0);
+                if (j < 0 || j >= nst) continue;
+                if (rev) j = nst - 1 - j;
+                run_item(ph, j, false);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(a.lock & 0x200)) __syncthreads();
+            local += 2;
+            continue;
+        }
+#endif
         for (int ph = 0; ph < 2 && !dead; ph++, local++) {
             const unsigned int phase = (unsigned int)(a.phase0 + local);
             // ---- neighbours through the edge part of the previous phase?  then drop what this CU's L1 still holds of their rows
-            if (wave == 0 && !a.nosync) {
+            if (wave == 0 && !nosync) {
                 bool ok = true;
                 if (phase > 0 && lane < nnb) {
                     const unsigned int *pf = a.flags + (size_t)h.nb[lane] * 32;
@@ -196,7 +249,7 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                 int old = 0;
                 if (lane == 0) old = atomicAdd(&edge_done, 1);
                 old = __builtin_amdgcn_readfirstlane(old);
-                if (old + 1 == nw * (local + 1) && lane == 0 && !a.nosync)
+                if (old + 1 == nw * (local + 1) && lane == 0 && !nosync)
                     __hip_atomic_store(my_flag, phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 reported = true;
             };
@@ -206,30 +259,7 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                 if (tr && lane == 0 && tr_k < 9) tr[tr_k++] = __builtin_amdgcn_s_memrealtime();
 #endif
                 if (j >= n_edge && !reported) report();
-                const uint32_t d = segs[j];
-                const Cell c = cell_of(d);
-                acc.cell = lbase + j * BX + lane;
-                const bool xband = (d & kSegXband) != 0 && !a.nosync;  // wave-uniform
-                if (ph == 0) {
-                    // phase A: reverse-time velocity (+ rho imaging, frame restore) + adjoint stress of the previous step
-                    if (xband) {
-                        velocity_body<false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
-                        stress_adj_body<MemAgent>(gs, c, adj, m, md, pc);
-                    } else {
-                        velocity_body<false>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc);
-                        stress_adj_body(gs, c, adj, m, md, pc);
-                    }
-                } else {
-                    // phase B: source_grad + reverse-time stress (+ lambda/mu imaging, frame restore) + adjoint velocity + injection
-                    if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
-                    if (xband) {
-                        stress_body<false, false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
-                        velocity_adj_body<MemAgent>(gs, c, adj, m, md, pc, lr);
-                    } else {
-                        stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
-                        velocity_adj_body(gs, c, adj, m, md, pc, lr);
-                    }
-                }
+                run_item(ph, j, !nosync);
             }
 #ifdef SEPFWI_PK_TRACE
             if (tr && lane == 0) tr[9] = __builtin_amdgcn_s_memrealtime();

@@ -54,7 +54,7 @@ std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w
         for (int s0 = 0; s0 < nseg; s0 += strip_w, strip++) {
             const int s1 = std::min(nseg, s0 + strip_w);
             for (int rr = 0; rr < r1 - r0; rr++) {
-                const int z = (strip & 1) ? r1 - 1 - rr : r0 + rr;  // alternate direction: a run that crosses strips stays compact
+                const int z = ((strip & 1) && cost.snake) ? r1 - 1 - rr : r0 + rr;  // alternate direction: a run that crosses strips stays compact
                 for (int xs = s0; xs < s1; xs++) {
                     const long long w = seg_cost(z, xs);
                     const int t = b * p.per_band + (int)std::min<long long>(p.per_band - 1, (k + w / 2) * p.per_band / total);

@@ -49,6 +49,7 @@ struct PlanCost {
     int nx = 0, npml = 0;            // grid width in cells, layer thickness; nx = 0: no weighting
     int w_xpml = 100, w_xpure = 100, w_zpml = 100;  // percent
     const int *band_w = nullptr;     // [nband] percent, or null
+    bool snake = true;               // strips walked top-down / bottom-up alternately (false: all top-down -- an experiment, -DSEPFWI_PROBES)
 };
 std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true,
                               const PlanCost &cost = PlanCost());

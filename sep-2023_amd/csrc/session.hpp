@@ -183,7 +183,7 @@ class Session {
         unsigned int *d_sync = nullptr;  // [nwg x 32 flag words | 8 band XCC ids | arrived | err]
         float *d_stf = nullptr;
         int *h_err = nullptr;            // pinned
-        int nwg = 0, threads = 0, lmask = 0, lmask_req = -1, wpc = 0, strip_w = 0, order = -1, wx = -1, wxp = -1, wz = -1;
+        int nwg = 0, threads = 0, lmask = 0, lmask_req = -1, wpc = 0, strip_w = 0, order = -1, wx = -1, wxp = -1, wz = -1, snake = -1;
         size_t lds_bytes = 0;
         int state = -1;                  // -1 not examined for this configuration, 0 the two-launch step is used, 1 ready
         std::string why;                 // when state == 0

@@ -336,135 +336,6 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
     }
 }
 
-// ---- the backward pass of one shot as ONE persistent launch ----------------------------------------------------------------
-// Can this call's configuration run k_bwd_persist?  Decided once per (workgroups per CU, waves, strip width, LDS mask): the tiling
-// is built and uploaded and the LDS-resident accumulators are chosen to fit.  Whether the grid really is resident at once (and every
-// band on one XCD) is decided by the start rendezvous of each pass (backward): a pass that does not start leaves everything
-// untouched, runs as per-step launches, and switches the session back to them.  Shots whose receivers are not a fused line of
-// channels need k_inject between the two halves of a step and never take the loop.
-bool Session::persist_ready(const Call &c, const ShotCtx &x) {
-    const KernelOptions &opt = c.opt;
-    if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
-    if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
-    Persist &k = pk_;
-    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask) {
-        if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
-        return k.state == 1;
-    }
-    k.state = 0;
-    k.wpc = opt.pk_wpc;
-    k.strip_w = opt.pk_px;
-    k.lmask_req = opt.pk_lmask;
-    int ncu = 0;
-    HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, gpu_id_));
-    const int nband = 8, nseg = (g_.nx + 63) / 64;
-    k.nwg = (ncu / nband) * nband * opt.pk_wpc;
-    k.threads = 64 * opt.pk_waves;
-    if (k.nwg <= 0 || (long long)g_.nzc * nseg < 4LL * k.nwg) {  // tiles of a handful of segments: the per-step launches (batched) are the better form
-        k.why = "grid too small for " + std::to_string(k.nwg) + " tiles";
-        return false;
-    }
-    PlanCost cost;
-    cost.nx = g_.nx;
-    cost.npml = g_.nPml;
-    cost.w_xpml = opt.pk_wx;
-    cost.w_xpure = opt.pk_wxp;
-    cost.w_zpml = opt.pk_wz;
-    k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
-    k.order = opt.pk_order;
-    k.wx = opt.pk_wx;
-    k.wxp = opt.pk_wxp;
-    k.wz = opt.pk_wz;
-    if (!k.why.empty()) return false;
-    // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a, b in that order)
-    const size_t lds_cu = 160 * 1024, per_wg = lds_cu / (size_t)opt.pk_wpc - 256;
-    const int masks[6] = {31, 15, 7, 3, 1, 0};  // (all five fit where a tile has at most 63 row segments: grids below the headline's size)
-    k.lmask = -1;
-    for (int mk : masks) {
-        if (opt.pk_lmask != 16 && mk != opt.pk_lmask) continue;
-        const size_t need = (size_t)__builtin_popcount(mk) * (size_t)k.plan.cap * 64 * sizeof(float);
-        if (need <= per_wg) {
-            k.lmask = mk;
-            k.lds_bytes = need;
-            break;
-        }
-    }
-    if (k.lmask < 0) {
-        k.why = "LDS accumulators do not fit";
-        return false;
-    }
-    auto refree = [](auto *&p) {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-    };
-    refree(k.d_seg);
-    refree(k.d_hdr);
-    refree(k.d_sync);
-    const size_t sync_words = (size_t)k.nwg * 32 + 16;
-    HIP_OK(dev_malloc((void **)&k.d_seg, k.plan.seg.size() * sizeof(uint32_t)));
-    HIP_OK(dev_malloc((void **)&k.d_hdr, k.plan.hdr.size() * sizeof(TileHdr)));
-    HIP_OK(dev_malloc((void **)&k.d_sync, sync_words * sizeof(unsigned int)));
-    if (!k.d_stf) HIP_OK(dev_malloc((void **)&k.d_stf, (size_t)par_.nSteps * sizeof(float)));
-    if (!k.h_err) HIP_OK(hipHostMalloc((void **)&k.h_err, 4 * sizeof(int), hipHostMallocDefault));
-    HIP_OK(hipMemcpy(k.d_seg, k.plan.seg.data(), k.plan.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(k.d_hdr, k.plan.hdr.data(), k.plan.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
-    k.state = 1;
-    k.why.clear();
-    return true;
-}
-
-void Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
-    Persist &k = pk_;
-    const int nSteps = par_.nSteps;
-    hipStream_t st = L.s;
-    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
-    int *err = (int *)(band_xcc + 10);
-    HIP_OK(hipMemsetAsync(k.d_sync, 0, ((size_t)k.nwg * 32 + 16) * sizeof(unsigned int), st));
-    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
-    HIP_OK(hipMemcpyAsync(k.d_stf, x.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, st));
-    PersistArgs a{};
-    ShotDev &d = a.s;
-    d.fields = x.state;
-    d.frame = x.frame;
-    d.stf = k.d_stf;
-    d.bmem = L.bm.dvz_dz;
-    d.adj = L.adj.vz;
-    d.acc = L.acc.lam;
-    d.res = x.res;
-    d.stf_grad = stf_grad_ + (size_t)x.is * nSteps;
-    d.z_src = x.sh->z_src;
-    d.x_src = x.sh->x_src;
-    d.lr_z = x.line.z;
-    d.lr_x0 = x.line.x0;
-    d.lr_n = x.line.n;
-    d.nrec = x.nrec;
-    d.src_rxz = (float)x.sh->src_rxz;
-    a.media = md_.lam;
-    a.cz = pc_.a_z;
-    a.n = cells_;
-    a.it_hi = nSteps - 2;
-    a.it_lo = 0;
-    a.src_scale = c.src_scale;
-    a.img_every = c.opt.img_every;
-    a.nband = k.plan.nband;
-    a.per_band = k.plan.per_band;
-    a.cap = k.plan.cap;
-    a.seg = k.d_seg;
-    a.hdr = k.d_hdr;
-    a.flags = k.d_sync;
-    a.band_xcc = band_xcc;
-    a.err = err;
-    a.phase0 = 0;
-    a.nosync = c.opt.pk_nosync;
-    a.prio = c.opt.pk_prio;
-    const int rc = launch_bwd_persist(st, g_, c.opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
-    if (rc != 0) throw HipError("persistent backward loop could not be launched (code " + std::to_string(rc) + ")");
-    launches_++;
-    persist_steps_ += (long long)(nSteps - 1);
-    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));  // both read after the pass's synchronisation (backward)
-    HIP_OK(hipMemcpyAsync(k.h_err + 1, band_xcc + 9, sizeof(int), hipMemcpyDeviceToHost, st));
-}
-
 void Session::backward(Call &c, const ShotCtx &x) {
     hipStream_t st = c.st;
     const BwdLane L{st, mem_, adj_, acc_};
@@ -563,170 +434,6 @@ void Session::run_streams(Call &c) {
             for (int k = 0; k < np; k++) backward(c, ctx[k]);
         is += np;
     }
-}
-
-// ---- batched schedule: every launch advances a whole batch of shots (grids that are not the headline's: launch-bound) --------
-// Bf shots share a forward launch, Bb <= Bf a backward launch; per-shot pointers and scalars in a device table (ShotDev).
-void Session::run_batched(Call &c, int Bf, int Bb) {
-    hipStream_t st = c.st;
-    const Grid &g = g_;
-    const KernelOptions &opt = c.opt;
-    const int nSteps = par_.nSteps, group_size = c.group_size;
-    const size_t n = cells_;
-    ensure_batch(Bf, c.with_adj ? Bb : 0, c.with_adj, group_size);
-    HIP_OK(hipMemcpyAsync(d_stf_, c.stf_rows.data(), (size_t)group_size * nSteps * sizeof(float), hipMemcpyHostToDevice, st));
-    const bool lf = opt.line_fuse != 0;
-    auto lane_ctx = [&](int is, bool with_obs) {  // shot `is` of the call in its batch lane
-        ShotCtx x = make_ctx(c, is, 0, st, with_obs);
-        const BLane &L = bl_[is % Bf];
-        if (x.quiet) x.quiet = quiet_slot(kMaxLanes + is % Bf);
-        use_state(x, L.state);
-        x.frame = L.frame;
-        x.syn = L.syn;
-        x.res = L.res;
-        return x;
-    };
-    std::vector<ShotDev> tab(group_size);
-    for (int is = 0; is < group_size; is++) {
-        const ShotCtx x = lane_ctx(is, false);
-        const BLane &LB = bl_[(is % Bf) % Bb];  // backward lane of this shot inside its sub-batch
-        ShotDev &d = tab[is];
-        d.fields = x.state;
-        d.mem = x.state + 5 * n;
-        d.frame = x.frame;
-        d.syn = x.syn;
-        d.stf = d_stf_ + (size_t)is * nSteps;
-        d.bmem = c.with_adj ? LB.bwd : nullptr;
-        d.adj = c.with_adj ? LB.bwd + 8 * n : nullptr;
-        d.acc = c.with_adj ? LB.bwd + 13 * n : nullptr;
-        d.res = x.res;
-        d.stf_grad = c.with_adj ? stf_grad_ + (size_t)is * nSteps : nullptr;
-        d.z_src = x.sh->z_src;
-        d.x_src = x.sh->x_src;
-        d.lr_z = x.line.z;
-        d.lr_x0 = x.line.x0;
-        d.lr_n = lf ? x.line.n : 0;
-        d.comps = x.comps | ((lf && x.line.n > 0 && !(x.comps & 1)) ? 16 : 0);  // bit 16: sample the line inside k_stress
-        d.nrec = x.nrec;
-        d.src_rxz = (float)x.sh->src_rxz;
-        d.quiet = x.quiet;
-    }
-    HIP_OK(hipMemcpyAsync(d_shots_, tab.data(), tab.size() * sizeof(ShotDev), hipMemcpyHostToDevice, st));
-    HIP_OK(hipStreamSynchronize(st));  // `tab` and `stf_rows` are pageable host memory
-    if (c.with_adj)
-        for (int k = 0; k < Bb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd + 13 * n, 0, 5 * n * sizeof(float), st));
-
-    for (int is0 = 0; is0 < group_size; is0 += Bf) {
-        const int nb = std::min(Bf, group_size - is0);
-        std::vector<ShotCtx> cx;
-        for (int k = 0; k < nb; k++) cx.push_back(lane_ctx(is0 + k, true));
-        // ---- forward time loop, libCUFD.cu:268-332
-        HIP_OK(hipEventRecord(ev_[0], st));
-        for (int k = 0; k < nb; k++) forward_init(cx[k]);
-        // the batch as up to three sub-batches on streams of their own (option batch_split): launches of different queues overlap
-        int ns = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nb));
-        for (int k = 0; k < nb; k++)
-            if (!(tab[is0 + k].comps & 16)) ns = 1;  // (general receivers are sampled by launches on the call's stream)
-        hipStream_t sub[kMaxLanes] = {st, nullptr, nullptr, nullptr};
-        if (ns > 1) {
-            for (int q = 1; q < ns; q++) {
-                XLane &L = xl_[q];
-                if (!L.stream) {
-                    HIP_OK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-                    HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
-                }
-                sub[q] = L.stream;
-            }
-            HIP_OK(hipEventRecord(ev_order_, st));
-            for (int q = 1; q < ns; q++) HIP_OK(hipStreamWaitEvent(sub[q], ev_order_, 0));
-        }
-        for (int it = 0; it <= nSteps - 2; it++) {
-            for (int q = 0; q < ns; q++) {
-                const int a0 = (int)((long long)nb * q / ns), a1 = (int)((long long)nb * (q + 1) / ns);
-                launch_stress_fwd_batch(sub[q], g, opt, d_shots_ + is0 + a0, a1 - a0, md_, pc_, n, data_len_, it, c.src_scale, c.with_adj);
-                launch_velocity_fwd_batch(sub[q], g, opt, d_shots_ + is0 + a0, a1 - a0, md_, pc_, n);
-                launches_ += 2;
-            }
-            for (int k = 0; k < nb; k++)
-                if (!(tab[is0 + k].comps & 16)) record_column(cx[k], it + 1);  // general receivers: sample the new state into column it+1
-        }
-        for (int q = 1; q < ns; q++) {
-            HIP_OK(hipEventRecord(xl_[q].join, sub[q]));
-            HIP_OK(hipStreamWaitEvent(st, xl_[q].join, 0));
-        }
-        for (int k = 0; k < nb; k++)
-            if (tab[is0 + k].comps & 16) record_column(cx[k], nSteps - 1);
-        if (c.if_res)
-            for (int k = 0; k < nb; k++) cond_on_ ? residual_conditioned(c, cx[k]) : residual(cx[k]);
-        HIP_OK(hipEventRecord(ev_[1], st));
-        fwd_steps_ += (long long)nb * (nSteps - 1);
-        HIP_OK(hipStreamSynchronize(st));
-        {
-            float ms = 0.f;
-            HIP_OK(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-            fwd_ms_ += ms;
-        }
-        obs_->release_all();
-        for (int k = 0; k < nb; k++) after_forward(c, cx[k]);
-        // ---- backward time loops in sub-batches, libCUFD.cu:500-675
-        for (int kb = 0; c.with_adj && kb < nb; kb += Bb) {
-            const int nbb = std::min(Bb, nb - kb);
-            HIP_OK(hipEventRecord(ev_[2], st));
-            for (int k = 0; k < nbb; k++) HIP_OK(hipMemsetAsync(bl_[k].bwd, 0, 13 * n * sizeof(float), st));  // memories + adjoint fields
-            for (int k = 0; k < nbb; k++)
-                if (cx[kb + k].quiet) HIP_OK(hipMemsetAsync(cx[kb + k].quiet + 2 * (size_t)g.qn, 0, 2 * (size_t)g.qn * sizeof(unsigned int), st));
-            int nsb = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nbb));  // sub-batches on streams of their own, as in the forward loop
-            for (int k = 0; k < nbb; k++)
-                if (tab[is0 + kb + k].lr_n == 0) nsb = 1;  // (k_inject runs on the call's stream)
-            if (nsb > 1) {
-                for (int q = 1; q < nsb; q++) {
-                    XLane &L = xl_[q];
-                    if (!L.stream) {
-                        HIP_OK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-                        HIP_OK(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
-                    }
-                    sub[q] = L.stream;
-                }
-                HIP_OK(hipEventRecord(ev_order_, st));
-                for (int q = 1; q < nsb; q++) HIP_OK(hipStreamWaitEvent(sub[q], ev_order_, 0));
-            }
-            for (int it = nSteps - 2; it >= 0; it--) {
-                hipEvent_t *ev = probe_pair(c, it);
-                Grid gs = g;
-                if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
-                for (int q = 0; q < nsb; q++) {
-                    const int a0 = (int)((long long)nbb * q / nsb), a1 = (int)((long long)nbb * (q + 1) / nsb);
-                    launch_bwd_a_batch(sub[q], gs, opt, d_shots_ + is0 + kb + a0, a1 - a0, md_, pc_, n, it);
-                    launch_bwd_b_batch(sub[q], gs, opt, d_shots_ + is0 + kb + a0, a1 - a0, md_, pc_, n, it, c.src_scale, (ev && q == 0) ? ev[0] : nullptr,
-                                       (ev && q == 0) ? ev[1] : nullptr);
-                    launches_ += 2;
-                }
-                for (int k = 0; k < nbb; k++)
-                    if (tab[is0 + kb + k].lr_n == 0) {
-                        const ShotCtx &x = cx[kb + k];
-                        const Fields adj = Fields{bl_[k].bwd + 8 * n, bl_[k].bwd + 9 * n, bl_[k].bwd + 10 * n, bl_[k].bwd + 11 * n, bl_[k].bwd + 12 * n};
-                        launch_inject(st, g, adj, x.nrec, x.rec, x.res + (size_t)it * x.nrec, x.sens);
-                        launches_++;
-                    }
-            }
-            for (int q = 1; q < nsb; q++) {
-                HIP_OK(hipEventRecord(xl_[q].join, sub[q]));
-                HIP_OK(hipStreamWaitEvent(st, xl_[q].join, 0));
-            }
-            HIP_OK(hipEventRecord(ev_[3], st));
-            bwd_steps_ += (long long)nbb * (nSteps - 1);
-            HIP_OK(hipStreamSynchronize(st));
-            collect_probes(c);
-            float ms = 0.f;
-            HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
-            bwd_ms_ += ms;
-        }
-    }
-    if (c.with_adj)  // the batch lanes' accumulators -> the session's (zeroed in prepare_buffers), summed in lane order
-        for (int k = 0; k < Bb; k++) {
-            launch_add_inplace(st, acc_.lam, bl_[k].bwd + 13 * n, 5 * n);
-            launches_++;
-        }
 }
 
 // ---- outputs: written in place when they live on this device, staged otherwise (host memory, another GPU) ------------------

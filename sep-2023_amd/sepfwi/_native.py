@@ -4,6 +4,7 @@ There is no CPU fallback: if the library cannot be loaded every operator call ra
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -12,11 +13,18 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # sep-2023_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
+# The same sources built with -DSEPFWI_PROBES: sepfwi_set_option then also knows the tuning knobs (tile shapes, wave counts, launch
+# structures) and the timing-only switches that the shipped library does not expose (include/sepfwi.h).  Used by scripts/ab_bench.py
+# and by the tests that prove every selectable kernel structure bit-identical; never by the operators unless asked to (use_variant).
+PROBES_LIB_PATH = os.path.join(_ROOT, "libsepfwi_probes.so")
+VARIANTS = {"default": (LIB_PATH, []), "probes": (PROBES_LIB_PATH, ["-DSEPFWI_PROBES"])}
+PUBLIC_OPTIONS = ("bwd_fuse", "batch", "img_every", "quiet_skip", "obs_cache_mb", "probe")
 SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "config.cpp", "capi.cpp"]
 HEADERS = ["kernels.hpp", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
-_lib = None
+_libs = {}
+_active = os.environ.get("SEPFWI_LIB_VARIANT", "default")
 
 
 class Stats(C.Structure):
@@ -28,40 +36,54 @@ class Stats(C.Structure):
                 ("obs_device_bytes", C.c_longlong), ("obs_host_bytes", C.c_longlong), ("obs_evictions", C.c_longlong), ("persist_steps", C.c_longlong), ("quiet_active", C.c_longlong), ("quiet_total", C.c_longlong)]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def needs_build(variant: str = "default") -> bool:
+    path = VARIANTS[variant][0]
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 ... (cross-compiles without a GPU; ~15 s)."""
-    if not (force or needs_build()):
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = False, variant: str = "all") -> str:
+    """hipcc --offload-arch=gfx950 ... (cross-compiles without a GPU; ~30 s per variant)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -ffp-contract=off: no fused multiply-adds chosen per kernel by the compiler, so every kernel structure (stream, batched,
-    # unfused, persistent) gives bit-identical results; the kernels are memory-bound, it costs nothing (DESIGN.md 3.4)
-    extra = os.environ.get("SEPFWI_HIPCC_FLAGS", "").split()   # experiments only (e.g. -fgpu-flush-denormals-to-zero)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + extra + ["-o", LIB_PATH] + SOURCES + ["-ldl"]   # hipFFT is opened lazily (csrc/conditioning.hip)
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    for name in (VARIANTS if variant == "all" else (variant,)):
+        path, flags = VARIANTS[name]
+        if not (force or needs_build(name)):
+            continue
+        # -ffp-contract=off: no fused multiply-adds chosen per kernel by the compiler, so every kernel structure (stream, batched,
+        # unfused, persistent) gives bit-identical results; the kernels are memory-bound, it costs nothing (DESIGN.md 3.4)
+        extra = os.environ.get("SEPFWI_HIPCC_FLAGS", "").split()   # experiments only (e.g. -fgpu-flush-denormals-to-zero)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"] + flags + extra + ["-o", path] + SOURCES + ["-ldl"]   # hipFFT is opened lazily (csrc/conditioning.hip)
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
     return LIB_PATH
+
+
+@contextlib.contextmanager
+def use_variant(name: str):
+    """Route every operator call of the block to another build of the library (its own sessions and option block)."""
+    global _active
+    prev, _active = _active, name
+    try:
+        yield lib()
+    finally:
+        _active = prev
 
 
 def lib():
     """The loaded library (ctypes.CDLL) with argument types declared."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    if _active in _libs:
+        return _libs[_active]
+    path = VARIANTS[_active][0]
     # torch first: both link libamdhip64.so.7 and must share ONE HIP runtime in the process.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise RuntimeError(
-            "libsepfwi.so is not built (%s missing). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
-            "there is no CPU fallback for the propagator." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "%s is not built (%s missing). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback for the propagator." % (os.path.basename(path), path))
+    L = C.CDLL(path)
     fp, ip = C.c_void_p, C.c_void_p
     L.sepfwi_last_error.restype = C.c_char_p
     L.sepfwi_cufd.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, ip, C.c_char_p]
@@ -82,7 +104,7 @@ def lib():
         getattr(L, f).restype = C.c_int
     L.sepfwi_release_all.restype = None
     L.sepfwi_invalidate_observed.restype = None
-    _lib = L
+    _libs[_active] = L
     return L
 
 

@@ -109,18 +109,31 @@ def rel_l2(a, b):
 
 # defaults of struct KernelOptions (csrc/kernels.hpp); `probe` is bench.py's business
 OPTION_DEFAULTS = dict(bz=2, xcd_remap=1, bwd_fuse=4, line_fuse=1, pair_fwd=1, fwd_lanes=3, early=0, rho_fly=1, amu_fly=1,
-                       rk_lazy=1, batch=2, batch_f=0, batch_b=0, batch_mb=200, batch_order=1, batch_split=2, img_every=1, obs_cache_mb=0, quiet_skip=0, quiet_rows=4, pk_lmask=16, pk_wpc=2, pk_px=3, pk_nosync=0, pk_waves=16, pk_order=1, pk_prio=1, pk_wx=150, pk_wxp=150, pk_wz=115)
+                       rk_lazy=1, batch=2, batch_f=0, batch_b=0, batch_mb=200, batch_order=1, batch_split=2, img_every=1, obs_cache_mb=0, quiet_skip=0, quiet_rows=4, pk_lmask=16, pk_wpc=2, pk_px=3, pk_nosync=0, pk_lock=0, pk_snake=1, pk_waves=16, pk_order=1, pk_prio=1, pk_wx=150, pk_wxp=150, pk_wz=115)
+
+
+def _needs_probes(opts):
+    from sepfwi import _native
+    return any(k not in _native.PUBLIC_OPTIONS for k in opts)
 
 
 @contextlib.contextmanager
 def kernel_options(**opts):
-    """Process-wide kernel options for the duration of a block, defaults restored afterwards."""
+    """Process-wide kernel options for the duration of a block, defaults restored afterwards.  Options the shipped library does not
+    expose (everything but _native.PUBLIC_OPTIONS: tile shapes, launch structures, ...) route the block to the -DSEPFWI_PROBES build of
+    the same sources (libsepfwi_probes.so), which has its own sessions and its own option block; a test whose blocks share a session
+    (observed data stored in it, statistics) asks for the `probes_lib` fixture instead and runs on that build from start to end."""
     from sepfwi import _native
-    L = _native.lib()
-    try:
-        for k, v in opts.items():
-            _native.check(L.sepfwi_set_option(k.encode(), int(v)))
-        yield
-    finally:
-        for k, v in OPTION_DEFAULTS.items():
-            L.sepfwi_set_option(k.encode(), int(v))
+    switched = _needs_probes(opts) and _native._active != "probes"
+    variant = "probes" if (switched or _native._active == "probes") else "default"
+    with _native.use_variant(variant) as L:
+        try:
+            for k, v in opts.items():
+                _native.check(L.sepfwi_set_option(k.encode(), int(v)))
+            yield
+        finally:
+            for k, v in OPTION_DEFAULTS.items():
+                if variant == "probes" or k in _native.PUBLIC_OPTIONS:
+                    L.sepfwi_set_option(k.encode(), int(v))
+            if switched:
+                L.sepfwi_release_all()      # nothing of a probe session outlives its block (HBM)

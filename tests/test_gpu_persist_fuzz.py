@@ -16,7 +16,7 @@ _SEEDS = list(range(int(os.environ.get("SEPFWI_PFUZZ_N", "6"))))
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
-def test_persistent_loop_random_geometry_is_bit_identical(tmp_path, hip_ops, seed):
+def test_persistent_loop_random_geometry_is_bit_identical(tmp_path, hip_ops, seed, probes_lib):
     rng = np.random.default_rng(4000 + seed)
     nPml = int(rng.integers(6, 33))
     # at least 4 x 512 row segments of 64 columns, i.e. every one of the 512 tiles gets a handful; aspect from 1 : 12 to 12 : 1

@@ -28,7 +28,7 @@ def _gathers(pb):
 
 @pytest.mark.parametrize("mode", [dict(batch=0), dict(batch=0, pair_fwd=0), dict(batch=1), dict(batch=1, batch_f=2, batch_b=1),
                                   dict(batch=0, bwd_fuse=2, img_every=2), dict(batch=0, early=3, bwd_fuse=2)])
-def test_quiet_skip_changes_nothing(tmp_path, hip_ops, mode):
+def test_quiet_skip_changes_nothing(tmp_path, hip_ops, mode, probes_lib):
     pb = P.make_problem(str(tmp_path), nz=260, nx=900, nPml=12, nSteps=420, nshots=3, hetero=True, rec_z=30)   # the front crosses a third of the grid
     lt, mt, dt_ = pb["lame_true"]
     lam, mu, den = pb["lame_init"]
@@ -74,7 +74,7 @@ _SEEDS = list(range(int(os.environ.get("SEPFWI_QFUZZ_N", "5"))))
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
-def test_quiet_skip_random_geometry(tmp_path, hip_ops, seed):
+def test_quiet_skip_random_geometry(tmp_path, hip_ops, seed, probes_lib):
     """Seeded random grids, layer widths, record lengths, source and fibre depths, launch structures: with and without the option the
     same bits.  One-off sweeps: SEPFWI_QFUZZ_N=300 (profiles/r05_quiet_fuzz.txt)."""
     rng = np.random.default_rng(7000 + seed)

@@ -25,6 +25,29 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert isinstance(L.sepfwi_last_error(), bytes)
 
 
+def test_shipped_library_knows_only_the_public_options():
+    """include/sepfwi.h: the shipped library accepts the six user options and nothing else -- the tuning knobs and, above all, the
+    timing-only switches that give WRONG results (pk_nosync, pk_lock) are unknown names there; they exist only in the
+    -DSEPFWI_PROBES build of the same sources, which the A/B scripts and the structure tests load explicitly."""
+    from sepfwi import _native
+    L = _native.lib()
+    assert set(_native.PUBLIC_OPTIONS) == {"bwd_fuse", "batch", "img_every", "quiet_skip", "obs_cache_mb", "probe"}
+    for name in _native.PUBLIC_OPTIONS:
+        v = L.sepfwi_get_option(name.encode())
+        assert v >= 0 and L.sepfwi_set_option(name.encode(), v) == 0, name
+    hidden = [k for k in P.OPTION_DEFAULTS if k not in _native.PUBLIC_OPTIONS]
+    assert "pk_nosync" in hidden and "pk_lock" in hidden and len(hidden) >= 20
+    for name in hidden:
+        assert L.sepfwi_get_option(name.encode()) == -1, name
+        assert L.sepfwi_set_option(name.encode(), P.OPTION_DEFAULTS[name]) == -1, name      # SEPFWI_EINVAL
+        assert b"unknown option" in L.sepfwi_last_error()
+    assert L.sepfwi_set_option(b"bwd_fuse", 3) == -1 and L.sepfwi_set_option(b"img_every", 0) == -1      # values are checked too
+    with _native.use_variant("probes") as LP:
+        for name, v in P.OPTION_DEFAULTS.items():
+            assert LP.sepfwi_get_option(name.encode()) == v, name
+            assert LP.sepfwi_set_option(name.encode(), v) == 0, name
+
+
 def test_library_does_not_link_hipfft():
     """hipFFT is opened with dlopen when the first FFT plan is made (csrc/conditioning.hip FftApi): it is not a DT_NEEDED entry, so
     a ROCm image without it still loads the propagator; the HIP runtime is the only ROCm library the loader must find."""
