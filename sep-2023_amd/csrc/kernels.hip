@@ -243,9 +243,13 @@ static void (*persist_kernel(int lmask))(Grid, const PersistArgs) {
     }
 }
 
-// 0, or why this grid cannot run the persistent loop (never launches a grid that would not be resident at once: its tiles wait for
-// each other)
-static int persist_config_ok(const void *k, int nwg, int threads, size_t lds_bytes) {
+// 0, or why this grid cannot run the persistent loop (never launch a grid that would not be resident at once: its tiles wait for
+// each other): -1 no kernel instance for this LDS mask, -2 the LDS request is refused, -3 the occupancy query fails, -4 fewer
+// workgroups fit the device than the grid has.  Asked ONCE per configuration (Session::persist_ready); it also raises the kernel's
+// dynamic-LDS limit, which the launches rely on.
+int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes) {
+    const void *k = (const void *)persist_kernel(lmask);
+    if (!k) return -1;
     if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds_bytes) != hipSuccess) return -3;
@@ -281,8 +285,6 @@ int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, c
         }
     }
 #endif
-    const int rc = persist_config_ok((const void *)k, nwg, threads, lds_bytes);
-    if (rc) return rc;
     if (ev_start)
         hipExtLaunchKernelGGL(k, dim3(nwg), dim3(threads), lds_bytes, st, ev_start, ev_stop, 0, g, args);
     else

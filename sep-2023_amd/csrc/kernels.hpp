@@ -73,8 +73,9 @@ void launch_bwd_a_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it);
 void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, const ShotDev *shots, int nb, Media md, PmlCoef pc,
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// persistent backward time loop (tiles: persist_plan.hpp): the launch (0, or < 0 when the grid cannot be resident at once / the LDS
-// does not fit).  args.census: the one-off rendezvous of a new configuration (every workgroup resident at once?  one XCD per band?)
+// persistent backward time loop (tiles: persist_plan.hpp).  persist_config_check: 0, or < 0 when this grid cannot be resident at once /
+// the LDS does not fit (once per configuration).  launch_bwd_persist: the launch of a checked configuration (0, or -1: no such kernel).
+int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes);
 int launch_bwd_persist(hipStream_t st, const Grid &g, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);

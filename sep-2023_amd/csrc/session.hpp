@@ -109,12 +109,21 @@ class Session {
     void backward(Call &c, const ShotCtx &x);
     // the same pass as ONE persistent launch (option bwd_fuse = 4; kernels.hip k_bwd_persist)
     bool persist_ready(const Call &c, const ShotCtx &x);
-    void backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L);
+    bool backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L);
+    void persist_demote(const std::string &why, int retry_in);
+    void persist_check_pass();
     hipEvent_t *probe_pair(Call &c, int it);
     void collect_probes(Call &c);
     // the two schedules of a call's shots
     void run_streams(Call &c);
+    // batched schedule (session_batched.cpp)
     void run_batched(Call &c, int Bf, int Bb);
+    ShotCtx batch_ctx(const Call &c, int is, int Bf, bool with_obs);
+    std::vector<ShotDev> batch_table(const Call &c, int Bf, int Bb);
+    void batch_streams(hipStream_t st, int ns, hipStream_t *sub);
+    void batch_join(hipStream_t st, int ns);
+    void batched_forward(Call &c, const std::vector<ShotDev> &tab, int is0, int nb, const std::vector<ShotCtx> &cx);
+    void batched_backward(Call &c, const std::vector<ShotDev> &tab, int first, int nbb, const ShotCtx *cx);
     void write_outputs(Call &c, float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den, float *grad_stf);
 
     std::string para_fname_;

@@ -1,0 +1,219 @@
+// session_persist.cpp -- host side of the persistent backward time loop (k_bwd_persist, kernels_persist.hpp):
+//   persist_ready         can this call's configuration run the loop?  (tiling, LDS budget, residency -- once per configuration)
+//   backward_persistent   one shot's backward pass as ONE launch; false when the loop did not start (nothing touched)
+//   persist_check_pass    after the pass: did a tile time out in flight?
+// The loop replaces the per-step launches of Session::backward_step (Src/libCUFD.cu:545-631, same order on every array).
+#include <cstdio>
+#include <cstring>
+
+#include "device_alloc.hpp"
+#include "hip_check.hpp"
+#include "kernels.hpp"
+#include "session.hpp"
+
+namespace sepfwi {
+
+// What the loop's tiling assumes of the device: gfx950's eight XCDs (one band of rows per XCD: blockIdx % 8 shares an L2) and
+// the LDS of its CUs, both asked of the device, not assumed.  Empty string, or why the loop is not for this device.
+static std::string persist_device(int gpu_id, int *ncu, size_t *lds_cu, int *nband) {
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, gpu_id));
+    *ncu = prop.multiProcessorCount;
+    *lds_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+    *nband = 8;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return std::string("device is ") + prop.gcnArchName + ", the loop's band-per-XCD tiling is gfx950's";
+    if (*ncu < *nband || *ncu % *nband) return "compute units are not a multiple of the 8 XCDs (a partitioned device)";
+    return "";
+}
+
+// Can this call's configuration run k_bwd_persist?  Decided once per (workgroups per CU, waves, strip width, cost weights, LDS
+// mask): the tiling is built and uploaded, the LDS-resident accumulators are chosen to fit, and the occupancy of that very
+// configuration is asked of the runtime -- a grid that cannot be resident at once is never marked ready.  Whether the grid really
+// is resident at once (the GPU may be shared) and every band sits on one XCD is decided by the start rendezvous of each pass
+// (backward_persistent): a pass that does not start leaves everything untouched and runs as per-step launches.
+bool Session::persist_ready(const Call &c, const ShotCtx &x) {
+    const KernelOptions &opt = c.opt;
+    if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
+    if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
+    Persist &k = pk_;
+    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx &&
+        k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask && k.snake == opt.pk_snake) {
+        if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
+        return k.state == 1;
+    }
+    k.state = 0;
+    k.wpc = opt.pk_wpc;
+    k.strip_w = opt.pk_px;
+    k.lmask_req = opt.pk_lmask;
+    k.order = opt.pk_order;
+    k.wx = opt.pk_wx;
+    k.wxp = opt.pk_wxp;
+    k.wz = opt.pk_wz;
+    k.snake = opt.pk_snake;
+    k.threads = 64 * opt.pk_waves;
+    int ncu = 0, nband = 0;
+    size_t lds_cu = 0;
+    k.why = persist_device(gpu_id_, &ncu, &lds_cu, &nband);
+    if (!k.why.empty()) return false;
+    const int nseg = (g_.nx + 63) / 64;
+    k.nwg = (ncu / nband) * nband * opt.pk_wpc;
+    if (k.nwg <= 0 || (long long)g_.nzc * nseg < 4LL * k.nwg) {  // tiles of a handful of segments: the per-step launches (batched) are the better form
+        k.why = "grid too small for " + std::to_string(k.nwg) + " tiles";
+        return false;
+    }
+    PlanCost cost;
+    cost.nx = g_.nx;
+    cost.npml = g_.nPml;
+    cost.w_xpml = opt.pk_wx;
+    cost.w_xpure = opt.pk_wxp;
+    cost.w_zpml = opt.pk_wz;
+    cost.snake = opt.pk_snake != 0;
+    k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
+    if (!k.why.empty()) return false;
+    // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a, b in that order)
+    const size_t per_wg = lds_cu / (size_t)opt.pk_wpc - 256;
+    const int masks[6] = {31, 15, 7, 3, 1, 0};  // (all five fit where a tile has at most 63 row segments: grids below the headline's size)
+    k.lmask = -1;
+    for (int mk : masks) {
+        if (opt.pk_lmask != 16 && mk != opt.pk_lmask) continue;
+        const size_t need = (size_t)__builtin_popcount(mk) * (size_t)k.plan.cap * 64 * sizeof(float);
+        if (need <= per_wg) {
+            k.lmask = mk;
+            k.lds_bytes = need;
+            break;
+        }
+    }
+    if (k.lmask < 0) {
+        k.why = "LDS accumulators do not fit";
+        return false;
+    }
+    const int rc = persist_config_check(k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
+    if (rc != 0) {
+        static const char *const kWhy[] = {"", "no kernel instance for this LDS mask", "the LDS request is refused", "the occupancy query failed",
+                                           "fewer workgroups fit the device than the grid has"};
+        k.why = std::string("configuration cannot be resident at once: ") + kWhy[rc >= -4 && rc < 0 ? -rc : 0] + " (code " + std::to_string(rc) + ")";
+        return false;
+    }
+    auto refree = [](auto *&p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    refree(k.d_seg);
+    refree(k.d_hdr);
+    refree(k.d_sync);
+    const size_t sync_words = (size_t)k.nwg * 32 + 16;
+    HIP_OK(dev_malloc((void **)&k.d_seg, k.plan.seg.size() * sizeof(uint32_t)));
+    HIP_OK(dev_malloc((void **)&k.d_hdr, k.plan.hdr.size() * sizeof(TileHdr)));
+    HIP_OK(dev_malloc((void **)&k.d_sync, sync_words * sizeof(unsigned int)));
+    if (!k.d_stf) HIP_OK(dev_malloc((void **)&k.d_stf, (size_t)par_.nSteps * sizeof(float)));
+    if (!k.h_err) HIP_OK(hipHostMalloc((void **)&k.h_err, 4 * sizeof(int), hipHostMallocDefault));
+    HIP_OK(hipMemcpy(k.d_seg, k.plan.seg.data(), k.plan.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(k.d_hdr, k.plan.hdr.data(), k.plan.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
+    k.state = 1;
+    k.why.clear();
+    return true;
+}
+
+// The loop is not used for this pass (and, unless `retry_in` says otherwise, for the rest of the session): say so once.
+void Session::persist_demote(const std::string &why, int retry_in) {
+    pk_.state = 0;
+    pk_.why = why;
+    pk_.retry_in = retry_in;
+    if (pk_.aborts++ == 0) fprintf(stderr, "sepfwi: persistent backward loop not started (%s); this pass runs as per-step launches\n", why.c_str());
+}
+
+// One shot's backward pass as one launch.  Returns false when the loop did not run -- the launch was refused, or the start
+// rendezvous found the grid not resident at once / a band spread over several XCDs: in both cases NOTHING has been touched, and the
+// caller runs the per-step launches.  Synchronises the stream (the verdict of the rendezvous is read on the host).
+bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
+    Persist &k = pk_;
+    const int nSteps = par_.nSteps;
+    hipStream_t st = L.s;
+    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
+    int *err = (int *)(band_xcc + 10);
+    HIP_OK(hipMemsetAsync(k.d_sync, 0, ((size_t)k.nwg * 32 + 16) * sizeof(unsigned int), st));
+    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
+    HIP_OK(hipMemcpyAsync(k.d_stf, x.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, st));
+    PersistArgs a{};
+    ShotDev &d = a.s;
+    d.fields = x.state;
+    d.frame = x.frame;
+    d.stf = k.d_stf;
+    d.bmem = L.bm.dvz_dz;
+    d.adj = L.adj.vz;
+    d.acc = L.acc.lam;
+    d.res = x.res;
+    d.stf_grad = stf_grad_ + (size_t)x.is * nSteps;
+    d.z_src = x.sh->z_src;
+    d.x_src = x.sh->x_src;
+    d.lr_z = x.line.z;
+    d.lr_x0 = x.line.x0;
+    d.lr_n = x.line.n;
+    d.nrec = x.nrec;
+    d.src_rxz = (float)x.sh->src_rxz;
+    a.media = md_.lam;
+    a.cz = pc_.a_z;
+    a.n = cells_;
+    a.it_hi = nSteps - 2;
+    a.it_lo = 0;
+    a.src_scale = c.src_scale;
+    a.img_every = c.opt.img_every;
+    a.nband = k.plan.nband;
+    a.per_band = k.plan.per_band;
+    a.cap = k.plan.cap;
+    a.seg = k.d_seg;
+    a.hdr = k.d_hdr;
+    a.flags = k.d_sync;
+    a.band_xcc = band_xcc;
+    a.err = err;
+    a.phase0 = 0;
+    a.nosync = c.opt.pk_nosync;
+    a.lock = c.opt.pk_lock;
+    a.prio = c.opt.pk_prio;
+    const int rc = launch_bwd_persist(st, g_, c.opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
+    if (rc != 0 || hipPeekAtLastError() != hipSuccess) {  // refused before anything ran: the two-launch step from now on
+        const hipError_t e = hipGetLastError();
+        persist_demote("the launch was refused (code " + std::to_string(rc) + (e != hipSuccess ? std::string(", ") + hipGetErrorString(e) : std::string()) + ")", 0);
+        return false;
+    }
+    launches_++;
+    HIP_OK(hipMemcpyAsync(k.h_err, err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(k.h_err + 1, band_xcc + 9, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (k.h_err[1] != (int)kPersistGo) {  // the loop did not start: this pass, and the session from now on, as per-step launches
+        const bool busy = k.h_err[1] != (int)kPersistAbortPlacement;
+        // transient contention: another try after 16 passes, three times at most
+        persist_demote(busy ? "the grid was not resident at once (GPU busy, or the configuration does not fit)" : "workgroups of one band run on several XCDs",
+                       busy && k.aborts < 3 ? 16 : 0);
+        return false;
+    }
+    persist_steps_ += (long long)(nSteps - 1);
+    return true;
+}
+
+// After a pass that ran in the loop: a wait inside the pass timed out (a tile's neighbour never published)?  The results are
+// discarded, the session goes back to the two-launch step and the call fails with where the tiles stood (the reference: exit(1),
+// Src/utilities.h:28-36).
+void Session::persist_check_pass() {
+    if (pk_.h_err[0] == 0) return;
+    std::vector<unsigned int> fl((size_t)pk_.nwg * 32);  // flags[tile] = phases whose edge part is complete
+    HIP_OK(hipMemcpy(fl.data(), pk_.d_sync, fl.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    unsigned int lo = ~0u, hi = 0;
+    int t_lo = 0, never = 0;
+    for (int t = 0; t < pk_.nwg; t++) {
+        const unsigned int v = fl[(size_t)t * 32];
+        if (v < lo) {
+            lo = v;
+            t_lo = t;
+        }
+        hi = std::max(hi, v);
+        never += v == 0;
+    }
+    pk_.state = 0;
+    pk_.why = "a pass failed";
+    throw HipError(std::string("persistent backward loop: a tile waited for its neighbour beyond the time limit") + " (results discarded; tiles reached phases " +
+                   std::to_string(lo) + " ... " + std::to_string(hi) + " of " + std::to_string(2 * (par_.nSteps - 1)) + ", slowest tile " + std::to_string(t_lo) + ", " +
+                   std::to_string(never) + " of " + std::to_string(pk_.nwg) + " never published)");
+}
+
+}  // namespace sepfwi

@@ -2,8 +2,9 @@
 //   prepare_media / prepare_buffers     set-up of one call (libCUFD.cu:39-165, the part that is not kept between calls)
 //   forward_*  / residual*              forward time loop of one shot and its misfit (libCUFD.cu:268-332, 410-427)
 //   after_forward                       seismogram files / HBM store / scratch dumps (libCUFD.cu:732-769)
-//   backward_* / backward               boundary-saving adjoint time loop of one shot (libCUFD.cu:500-675)
-//   run_streams / run_batched           the two schedules of a call's shots
+//   backward_* / backward               boundary-saving adjoint time loop of one shot (libCUFD.cu:500-675); as one persistent launch:
+//                                       session_persist.cpp
+//   run_streams                         the stream schedule of a call's shots; the batched one: session_batched.cpp
 //   write_outputs                       gradient finalisation and read-back (libCUFD.cu:710-724,775-779)
 #include <chrono>
 #include <cmath>
@@ -336,29 +337,18 @@ void Session::backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it)
     }
 }
 
+// The backward pass of one shot: ONE persistent launch where the configuration allows it (session_persist.cpp), else -- or when the
+// loop's start rendezvous says the grid is not resident at once, which leaves everything untouched -- one backward_step per time step.
 void Session::backward(Call &c, const ShotCtx &x) {
     hipStream_t st = c.st;
     const BwdLane L{st, mem_, adj_, acc_};
-    const bool persistent = persist_ready(c, x);
+    const bool eligible = persist_ready(c, x);
     HIP_OK(hipEventRecord(ev_[2], st));
     backward_init(L);
     if (x.quiet) HIP_OK(hipMemsetAsync(x.quiet + 2 * (size_t)g_.qn, 0, 2 * (size_t)g_.qn * sizeof(unsigned int), st));  // the adjoint maps
-    if (persistent) {
-        backward_persistent(c, x, L);
-        HIP_OK(hipStreamSynchronize(st));
-        if (pk_.h_err[1] != (int)kPersistGo) {  // the loop did not start (nothing touched): this pass, and the session from now on, as per-step launches
-            pk_.state = 0;
-            const bool busy = pk_.h_err[1] != (int)kPersistAbortPlacement;
-            pk_.why = busy ? "the grid was not resident at once (GPU busy, or the configuration does not fit)" : "workgroups of one band run on several XCDs";
-            pk_.retry_in = busy ? (pk_.aborts < 3 ? 16 : 0) : 0;  // transient contention: another try after 16 passes, three times at most
-            if (pk_.aborts++ == 0)
-                fprintf(stderr, "sepfwi: persistent backward loop not started (%s); this pass runs as per-step launches\n", pk_.why.c_str());
-            persist_steps_ -= (long long)(par_.nSteps - 1);
-            for (int it = par_.nSteps - 2; it >= 0; it--) backward_step(c, x, L, it);
-        }
-    } else {
+    const bool looped = eligible && backward_persistent(c, x, L);
+    if (!looped)
         for (int it = par_.nSteps - 2; it >= 0; it--) backward_step(c, x, L, it);
-    }
     HIP_OK(hipEventRecord(ev_[3], st));
     bwd_steps_ += (long long)(par_.nSteps - 1);
     HIP_OK(hipStreamSynchronize(st));
@@ -366,25 +356,7 @@ void Session::backward(Call &c, const ShotCtx &x) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     bwd_ms_ += ms;
-    if (persistent && pk_.h_err[0] != 0) {
-        // where the tiles stood: flags[tile] = phases whose edge part is complete
-        std::vector<unsigned int> fl((size_t)pk_.nwg * 32);
-        HIP_OK(hipMemcpy(fl.data(), pk_.d_sync, fl.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-        unsigned int lo = ~0u, hi = 0;
-        int t_lo = 0, never = 0;
-        for (int t = 0; t < pk_.nwg; t++) {
-            const unsigned int v = fl[(size_t)t * 32];
-            if (v < lo) { lo = v; t_lo = t; }
-            hi = std::max(hi, v);
-            never += v == 0;
-        }
-        pk_.state = 0;  // this session goes back to the two-launch step
-        pk_.why = "a pass failed";
-        throw HipError(std::string("persistent backward loop: a tile waited for its neighbour beyond the time limit") +
-                       " (results discarded; tiles reached phases " + std::to_string(lo) + " ... " + std::to_string(hi) + " of " +
-                       std::to_string(2 * (par_.nSteps - 1)) + ", slowest tile " + std::to_string(t_lo) + ", " + std::to_string(never) + " of " +
-                       std::to_string(pk_.nwg) + " never published)");
-    }
+    if (looped) persist_check_pass();
 }
 
 // ---- stream schedule: up to fwd_lanes forward passes side by side (their kernel-boundary gaps and tails fill each other:

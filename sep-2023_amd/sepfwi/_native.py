@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
 PROBES_LIB_PATH = os.path.join(_ROOT, "libsepfwi_probes.so")
 VARIANTS = {"default": (LIB_PATH, []), "probes": (PROBES_LIB_PATH, ["-DSEPFWI_PROBES"])}
 PUBLIC_OPTIONS = ("bwd_fuse", "batch", "img_every", "quiet_skip", "obs_cache_mb", "probe")
-SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "config.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "session_persist.cpp", "session_batched.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "config.cpp", "capi.cpp"]
 HEADERS = ["kernels.hpp", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
