@@ -345,7 +345,7 @@ def main():
         t0 = time.perf_counter()
         fwd_ms = bwd_ms = call_ms = 0.0
         probe_us, probe_n = 0.0, 0
-        persist_steps = 0
+        persist_steps = bwd_steps = 0
         for s in range(K):
             step(s)
             st = fwi_ops.stats(pb["para_fname"], local)
@@ -356,6 +356,7 @@ def main():
             probe_us += st["probe_kernel_us"] * st["probe_calls"]
             probe_n += st["probe_calls"]
             persist_steps += st.get("persist_steps", 0)
+            bwd_steps += st["bwd_steps"]
         torch.cuda.synchronize()
         if world > 1:
             td.barrier()
@@ -364,7 +365,14 @@ def main():
         coll = _dist.collective_stats(reset=True) if args.mode == "fwdadj" else None
         rank_ms = [call_ms / max(K, 1)]
         rank_ar = [coll["allreduce_ms"] if coll and coll["allreduce_ms"] is not None else 0.0]
+        # which share of this rank's backward time steps ran inside the persistent loop, and -- where not all of them did -- why not: a
+        # rank that fell back to per-step launches (its GPU shared with another job, say) is ~10 % slower and must not hide inside
+        # rank_ms_per_step.max
+        rank_loop = [persist_steps / float(bwd_steps) if bwd_steps else None]
+        rank_why = [fwi_ops.loop_status(pb["para_fname"], local) if args.mode == "fwdadj" else ""]
         if world > 1:
+            if td.get_world_size() != args.gpus:
+                raise SystemExit("bench.py: the %s group has %d ranks, --gpus says %d" % (td.get_backend(), td.get_world_size(), args.gpus))
             cdev = dev if args.backend == "nccl" else "cpu"
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -375,6 +383,10 @@ def main():
             td.all_gather(allr, mine)
             rank_ms = [float(a[0]) for a in allr]
             rank_ar = [float(a[1]) for a in allr]
+            gathered = [None] * world
+            td.all_gather_object(gathered, (rank_loop[0], rank_why[0]))
+            rank_loop = [g[0] for g in gathered]
+            rank_why = [g[1] for g in gathered]
 
         passes = 3 if args.mode == "fwdadj" else 1
         updates_per_shot = passes * pb["n_c"] * (args.nsteps - 1)
@@ -448,6 +460,11 @@ def main():
                                "bytes": coll["bytes"], "allreduce_ms": round(min(rank_ar), 4), "allreduce_ms_max": round(max(rank_ar), 4),
                                "staged_copies": coll["staged"], "devices": "shared device 0 (rehearsal)" if args.share_gpu else "one per rank"}
             out["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}
+            if args.mode == "fwdadj":
+                fr = [f for f in rank_loop if f is not None]
+                out["persistent_loop"] = {"share_of_bwd_steps_min": round(min(fr), 4) if fr else None,
+                                          "share_of_bwd_steps_per_rank": [None if f is None else round(f, 4) for f in rank_loop],
+                                          "why_not": {str(r): w for r, w in enumerate(rank_why) if w}}
             if world == 1 and args.mode == "fwdadj" and not args.no_call32 and args.nz == 1000 and args.nx == 2000:
                 # configs[2] literally: ONE fwi_ops.backward call over 32 shots on this GPU (outside the timed region above)
                 out["call32"] = call32(os.path.join(workdir, "call32"), args, dev, local)

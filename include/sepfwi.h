@@ -143,6 +143,14 @@ typedef struct sepfwi_stats {
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 
 /*
+ * Why the most recent backward passes of (para_fname, gpu_id) did NOT run in the persistent time loop -- "" while they did (or no
+ * gradient call has asked yet): the grid is too small for the loop's tiles, the configuration cannot be resident at once, the start
+ * rendezvous found the GPU busy, ...  Up to len - 1 characters into `why`, always terminated.  For multi-GPU runs: a rank that fell
+ * back to per-step launches is 10 % slower than its peers and must be visible (bench.py prints every rank's string).
+ */
+int sepfwi_loop_status(const char *para_fname, int gpu_id, char *why, int len);
+
+/*
  * Options (process-wide defaults; every sepfwi_cufd* call takes ONE snapshot of them when it starts).  Names, defaults, meaning:
  *   bwd_fuse 4    backward step: 0 the reference's four kernels + injection, 2 two fused launches, 4 the persistent time loop (else 2)
  *   batch 2       shots of a call: 0 one stream per forward lane, 1 batched launches, 2 chosen by grid size

@@ -1,6 +1,7 @@
 // capi.cpp -- the extern "C" surface declared in include/sepfwi.h.  Exceptions never cross it: every
 // failure becomes an error code plus a thread-local message (the reference printf()s and exit(1)s,
 // Src/utilities.h:28-36, which would take the Python interpreter down).
+#include <cstdio>
 #include <cstring>
 #include <initializer_list>
 #include <string>
@@ -123,6 +124,16 @@ int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out) {
         std::shared_ptr<Session> s = find_session(para_fname, gpu_id);
         if (!s) throw std::invalid_argument("no session for this parameter file / gpu");
         s->stats(out);
+    });
+}
+
+int sepfwi_loop_status(const char *para_fname, int gpu_id, char *why, int len) {
+    return guarded([&] {
+        if (!para_fname || !why || len < 1) throw std::invalid_argument("bad arguments");
+        std::shared_ptr<Session> s = find_session(para_fname, gpu_id);
+        if (!s) throw std::invalid_argument("no session for this parameter file / gpu");
+        const std::string w = s->loop_status();
+        std::snprintf(why, (size_t)len, "%s", w.c_str());
     });
 }
 

@@ -113,6 +113,20 @@ struct ShotDev {
     unsigned int *quiet;  // null, or the shot's four quiet-segment maps: forward velocity, forward stress, adjoint velocity, adjoint stress
 };
 
+// Adjoint-source injection inside the persistent backward loop for receivers that are not a fused horizontal line (inject_plan.hpp):
+// per row segment that holds target cells, the lanes that receive a value and where their values start in the per-time-step list.
+struct InjSeg {  // 32 bytes
+    int base[2];                 // index of the segment's first target: vx, vz
+    int pad[2];
+    unsigned long long mask[2];  // lanes (cells of the segment) that receive a value: vx, vz
+};
+struct InjArgs {
+    const int *lookup;     // [nzc * nseg] row segment -> InjSeg index or -1
+    const InjSeg *segs;
+    const float *val;      // [nSteps][ntgt]: the residual folded per target cell (k_inject_values)
+    int ntgt, nseg;
+};
+
 constexpr unsigned int kPersistGo = 1, kPersistAbortResidency = 2, kPersistAbortPlacement = 3;  // start rendezvous of k_bwd_persist
 
 // Argument block of the persistent backward time loop (k_bwd_persist), passed BY VALUE: pointers that arrive in the kernel-argument
@@ -137,6 +151,7 @@ struct PersistArgs {
     int nosync;              // -DSEPFWI_PROBES builds, timing experiments only: no waits, no flags, no agent-scope accesses (results wrong)
     int lock;                // -DSEPFWI_PROBES builds, timing experiments only: phases interleaved (option pk_lock)
     int prio;                // 1: wave priorities interleave the CU's two workgroups (kernels.hip)
+    InjArgs inj;             // k_bwd_persist<LMASK, true>: general receivers (else unused)
 };
 
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step

@@ -231,14 +231,14 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
-static void (*persist_kernel(int lmask))(Grid, const PersistArgs) {
+static void (*persist_kernel(int lmask, bool ginj))(Grid, const PersistArgs) {
     switch (lmask) {
-        case 0: return k_bwd_persist<0>;
-        case 1: return k_bwd_persist<1>;
-        case 3: return k_bwd_persist<3>;
-        case 7: return k_bwd_persist<7>;
-        case 15: return k_bwd_persist<15>;
-        case 31: return k_bwd_persist<31>;
+        case 0: return ginj ? k_bwd_persist<0, true> : k_bwd_persist<0>;
+        case 1: return ginj ? k_bwd_persist<1, true> : k_bwd_persist<1>;
+        case 3: return ginj ? k_bwd_persist<3, true> : k_bwd_persist<3>;
+        case 7: return ginj ? k_bwd_persist<7, true> : k_bwd_persist<7>;
+        case 15: return ginj ? k_bwd_persist<15, true> : k_bwd_persist<15>;
+        case 31: return ginj ? k_bwd_persist<31, true> : k_bwd_persist<31>;
         default: return nullptr;
     }
 }
@@ -248,22 +248,24 @@ static void (*persist_kernel(int lmask))(Grid, const PersistArgs) {
 // workgroups fit the device than the grid has.  Asked ONCE per configuration (Session::persist_ready); it also raises the kernel's
 // dynamic-LDS limit, which the launches rely on.
 int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes) {
-    const void *k = (const void *)persist_kernel(lmask);
-    if (!k) return -1;
-    if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds_bytes) != hipSuccess) return -3;
     int dev = 0, ncu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (per_cu * ncu < nwg) return -4;
+    for (int ginj = 0; ginj < 2; ginj++) {  // both instances of the configuration: fused line of channels / general receivers
+        const void *k = (const void *)persist_kernel(lmask, ginj != 0);
+        if (!k) return -1;
+        if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds_bytes) != hipSuccess) return -3;
+        if (per_cu * ncu < nwg) return -4;
+    }
     return 0;
 }
 
 int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
-    auto k = persist_kernel(lmask);
+    auto k = persist_kernel(lmask, args.inj.lookup != nullptr);
     if (!k) return -1;
 #ifdef SEPFWI_PK_TRACE
     {
@@ -361,6 +363,12 @@ void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const in
     if (nrec <= 0) return;
     hipLaunchKernelGGL(k_inject, dim3((nrec + 255) / 256), dim3(256), 0, st, adj, nrec, rec_idx, res_t, g.fiber ? g.pitch : 0,
                        sens, g.pitch, g.dx * g.rdz);
+}
+
+void launch_inject_values(hipStream_t st, const float *res, int nrec, int nSteps, const int *tgt_start, const int *ent_rec, const float *ent_w, int ntgt,
+                          float *val) {
+    if (ntgt <= 0 || nSteps <= 0) return;
+    hipLaunchKernelGGL(k_inject_values, dim3((ntgt + 255) / 256, nSteps), dim3(256), 0, st, res, nrec, tgt_start, ent_rec, ent_w, ntgt, val);
 }
 
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,

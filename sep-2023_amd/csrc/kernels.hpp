@@ -84,6 +84,9 @@ void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int 
 // sens: null (straight fibre along x, or along z when g.fiber) or nrec x 3 directional sensitivities (s_xx, s_zz, s_xz)
 void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const int *rec_idx, const float *res_t,
                    const float *sens = nullptr);
+// the residual [it][rec] folded per injection target and time step: val[it][t] = sum over the target's entries of w r[it][rec] (inject_plan.hpp)
+void launch_inject_values(hipStream_t st, const float *res, int nrec, int nSteps, const int *tgt_start, const int *ent_rec, const float *ent_w, int ntgt,
+                          float *val);
 void launch_residual(hipStream_t st, const float *obs, const float *syn, float *res, int nrec, long long n,
                      double *sumsq);
 void launch_transpose(hipStream_t st, const float *in, float *out, int rows, int cols);

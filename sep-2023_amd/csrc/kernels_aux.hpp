@@ -64,6 +64,19 @@ __global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, 
     }
 }
 
+// The adjoint source of the persistent loop for general receivers (inject_plan.hpp): one value per target cell and time step,
+//   val[it][t] = sum_e w_e res[it][rec_e]   over the target's entries in channel order
+// -- what k_inject's atomics add to that cell in that step, in a fixed order.  One thread per (target, time step).
+__global__ void k_inject_values(const float *__restrict__ res, int nrec, const int *__restrict__ tgt_start, const int *__restrict__ ent_rec,
+                                const float *__restrict__ ent_w, int ntgt, float *__restrict__ val) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, it = blockIdx.y;
+    if (t >= ntgt) return;
+    const float *r = res + (size_t)it * (size_t)nrec;
+    float s = 0.0f;
+    for (int e = tgt_start[t]; e < tgt_start[t + 1]; e++) s += ent_w[e] * r[ent_rec[e]];
+    val[(size_t)it * (size_t)ntgt + t] = s;
+}
+
 // residual r = obs - syn (time sample 0 forced to 0) and sum r^2, all time-major [it][rec].
 // One double partial per block -> atomicAdd(double).
 __global__ void k_residual(const float *__restrict__ obs, const float *__restrict__ syn, float *__restrict__ res,

@@ -47,7 +47,10 @@ constexpr int kPersistSpinLimit = 1 << 21;   // polls of ~1 us: about two second
 constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 
 // registers sized for 8 waves per SIMD: two workgroups of 16 waves per CU
-template <int LMASK>
+// GINJ: the shot's receivers are not a fused horizontal line (scattered or strided channels, a vertical fibre, directional
+// sensitivities): the residual of the step, folded per target cell beforehand (k_inject_values), is added by the lane that owns the
+// cell right after its adjoint-velocity update -- res_injection_exx / _ezz (Src/utilities.cu:605-641) without a launch of its own.
+template <int LMASK, bool GINJ = false>
 __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
     extern __shared__ float lds_dyn[];
     __shared__ int next_item, edge_done, abort_flag, start_verdict, cu_slot_s;
@@ -174,6 +177,27 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                 } else {
                     stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{});
                     velocity_adj_body(gs, c, adj, m, md, pc, lr);
+                }
+                if constexpr (GINJ) {
+                    // the step's adjoint source at the cells of this segment (rows and columns outside the updated region included:
+                    // the adjoint stress update reads them through its stencils)
+                    typedef const int __attribute__((address_space(4))) *ctab_t;
+                    const int slot = ((ctab_t)a.inj.lookup)[c.z * a.inj.nseg + (int)((d >> 16) & 0xffu)];
+                    if (slot >= 0 && c.x < g.nx) {
+                        const InjSeg q = a.inj.segs[slot];
+                        const float *val_t = a.inj.val + (size_t)it * (size_t)a.inj.ntgt;
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        if ((q.mask[0] >> lane) & 1ull) {
+                            const float v = val_t[q.base[0] + __popcll(q.mask[0] & below)];
+                            if (xband) MemAgent::st(&adj.vx[c.i], MemAgent::ld(&adj.vx[c.i]) + v);
+                            else adj.vx[c.i] += v;
+                        }
+                        if ((q.mask[1] >> lane) & 1ull) {
+                            const float v = val_t[q.base[1] + __popcll(q.mask[1] & below)];
+                            if (xband) MemAgent::st(&adj.vz[c.i], MemAgent::ld(&adj.vz[c.i]) + v);
+                            else adj.vz[c.i] += v;
+                        }
+                    }
                 }
             }
         };

@@ -231,6 +231,15 @@ Session::~Session() {
     if (pk_.d_sync) (void)hipFree(pk_.d_sync);
     if (pk_.d_stf) (void)hipFree(pk_.d_stf);
     if (pk_.h_err) (void)hipHostFree(pk_.h_err);
+    for (auto &kv : inj_) {
+        InjDev &d = kv.second;
+        (void)hipFree(d.lookup);
+        (void)hipFree(d.segs);
+        (void)hipFree(d.tgt_start);
+        (void)hipFree(d.ent_rec);
+        (void)hipFree(d.ent_w);
+    }
+    if (inj_val_) (void)hipFree(inj_val_);
     for (void *p : allocs_) (void)hipFree(p);
     if (frame_) (void)hipFree(frame_);
     if (stf_grad_) (void)hipFree(stf_grad_);

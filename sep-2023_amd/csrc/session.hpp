@@ -33,6 +33,7 @@ class Session {
              const float *Mu, const float *Den, const float *stf, int calc_id, int group_size, const int *shot_ids,
              hipStream_t ext_stream, bool async);
     void stats(sepfwi_stats *out) const;
+    std::string loop_status();  // "" while the persistent backward loop is in use, else why not (sepfwi_loop_status)
     void drop_observed();
     // observed axial strain of one shot from memory ([nrec][nSteps] like the files; host or device pointer)
     void set_observed(int shot_id, const float *ett, int nrec, int nSteps);
@@ -110,6 +111,7 @@ class Session {
     // the same pass as ONE persistent launch (option bwd_fuse = 4; kernels.hip k_bwd_persist)
     bool persist_ready(const Call &c, const ShotCtx &x);
     bool backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L);
+    void persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, InjArgs *out);
     void persist_demote(const std::string &why, int retry_in);
     void persist_check_pass();
     hipEvent_t *probe_pair(Call &c, int it);
@@ -198,6 +200,17 @@ class Session {
         std::string why;                 // when state == 0
         int retry_in = 0, aborts = 0;    // passes until the loop is tried again after a start rendezvous that failed; how often it did
     } pk_;
+    // adjoint-source injection inside the loop for shots whose receivers are not a fused line: the plan of each such shot (device
+    // copies, built on first use) and the pass's residual folded per target cell [nSteps][ntgt]
+    struct InjDev {
+        int *lookup = nullptr, *tgt_start = nullptr, *ent_rec = nullptr;
+        InjSeg *segs = nullptr;
+        float *ent_w = nullptr;
+        int ntgt = 0;
+    };
+    std::map<int, InjDev> inj_;
+    float *inj_val_ = nullptr;
+    size_t inj_val_len_ = 0;
     long long persist_steps_ = 0;
     long long quiet_active_ = 0, quiet_total_ = 0;
     unsigned int *quiet_last_ = nullptr;  // maps of the shot whose forward pass started last in this call

@@ -8,6 +8,7 @@
 
 #include "device_alloc.hpp"
 #include "hip_check.hpp"
+#include "inject_plan.hpp"
 #include "kernels.hpp"
 #include "session.hpp"
 
@@ -34,7 +35,7 @@ static std::string persist_device(int gpu_id, int *ncu, size_t *lds_cu, int *nba
 bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     const KernelOptions &opt = c.opt;
     if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
-    if (!(x.nrec == 0 || (x.line.n > 0 && opt.line_fuse != 0))) return false;
+    (void)x;  // every receiver geometry takes the loop: a fused line of channels inside the bodies, anything else through persist_inject
     Persist &k = pk_;
     if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx &&
         k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask && k.snake == opt.pk_snake) {
@@ -114,6 +115,55 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     return true;
 }
 
+// Adjoint source of a shot whose receivers are not a fused horizontal line (strided or scattered channels, a vertical fibre,
+// directional sensitivities): the injection plan of the shot (built once per session and shot, inject_plan.hpp) and the residual of
+// THIS pass folded per target cell and time step (one launch).  Fills a.inj; leaves it empty for a fused line or no receivers.
+void Session::persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, InjArgs *out) {
+    *out = InjArgs{};
+    if (x.nrec == 0 || (x.line.n > 0 && c.opt.line_fuse != 0)) return;
+    auto it = inj_.find(x.id);
+    if (it == inj_.end()) {
+        const Shot &sh = *x.sh;
+        const InjectPlan p = make_inject_plan(sh.nrec, sh.z_rec.data(), sh.x_rec.data(), sh.sens.empty() ? nullptr : sh.sens.data(), par_.fiber != 0,
+                                              g_.dx * g_.rdz, g_.nzc, g_.nx);
+        InjDev d;
+        d.ntgt = p.ntgt;
+        auto up = [&](auto **dst, const auto &v) {
+            HIP_OK(dev_malloc((void **)dst, std::max<size_t>(1, v.size()) * sizeof(v[0])));
+            if (!v.empty()) HIP_OK(hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+            device_bytes_ += (long long)(v.size() * sizeof(v[0]));
+        };
+        up(&d.lookup, p.lookup);
+        up(&d.segs, p.segs);
+        up(&d.tgt_start, p.tgt_start);
+        up(&d.ent_rec, p.ent_rec);
+        up(&d.ent_w, p.ent_w);
+        it = inj_.emplace(x.id, d).first;
+    }
+    const InjDev &d = it->second;
+    const size_t need = (size_t)par_.nSteps * (size_t)std::max(1, d.ntgt);
+    if (need > inj_val_len_) {
+        if (inj_val_) (void)hipFree(inj_val_);
+        inj_val_ = nullptr;
+        HIP_OK(dev_malloc((void **)&inj_val_, need * sizeof(float)));
+        device_bytes_ += (long long)((need - inj_val_len_) * sizeof(float));
+        inj_val_len_ = need;
+    }
+    launch_inject_values(st, x.res, x.nrec, par_.nSteps, d.tgt_start, d.ent_rec, d.ent_w, d.ntgt, inj_val_);
+    launches_++;
+    out->lookup = d.lookup;
+    out->segs = d.segs;
+    out->val = inj_val_;
+    out->ntgt = d.ntgt;
+    out->nseg = (g_.nx + 63) / 64;
+}
+
+std::string Session::loop_status() {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (pk_.state < 0) return "not considered yet (no gradient call, the batched schedule, or bwd_fuse != 4)";
+    return pk_.state == 1 ? std::string() : pk_.why;
+}
+
 // The loop is not used for this pass (and, unless `retry_in` says otherwise, for the rest of the session): say so once.
 void Session::persist_demote(const std::string &why, int retry_in) {
     pk_.state = 0;
@@ -170,6 +220,7 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     a.nosync = c.opt.pk_nosync;
     a.lock = c.opt.pk_lock;
     a.prio = c.opt.pk_prio;
+    persist_inject(c, x, st, &a.inj);
     const int rc = launch_bwd_persist(st, g_, c.opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
     if (rc != 0 || hipPeekAtLastError() != hipSuccess) {  // refused before anything ran: the two-launch step from now on
         const hipError_t e = hipGetLastError();

@@ -19,8 +19,8 @@ LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
 PROBES_LIB_PATH = os.path.join(_ROOT, "libsepfwi_probes.so")
 VARIANTS = {"default": (LIB_PATH, []), "probes": (PROBES_LIB_PATH, ["-DSEPFWI_PROBES"])}
 PUBLIC_OPTIONS = ("bwd_fuse", "batch", "img_every", "quiet_skip", "obs_cache_mb", "probe")
-SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "session_persist.cpp", "session_batched.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "config.cpp", "capi.cpp"]
-HEADERS = ["kernels.hpp", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
+SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "session_persist.cpp", "session_batched.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "inject_plan.cpp", "config.cpp", "capi.cpp"]
+HEADERS = ["kernels.hpp", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "inject_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
            os.path.join("..", "..", "include", "sepfwi.h")]
 
 _libs = {}
@@ -97,9 +97,10 @@ def lib():
     L.sepfwi_param_forward.argtypes = [C.c_int] * 5 + [fp] * 10 + [C.c_void_p]
     L.sepfwi_param_backward.argtypes = [C.c_int] * 5 + [fp] * 13 + [C.c_void_p]
     L.sepfwi_debug_field.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, fp]
+    L.sepfwi_loop_status.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.sepfwi_set_observed.argtypes = [C.c_char_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
     for f in ("sepfwi_cufd", "sepfwi_cufd_stream", "sepfwi_cpml_profiles", "sepfwi_stf_taper", "sepfwi_shot_split",
-              "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_get_option", "sepfwi_debug_field", "sepfwi_set_observed",
+              "sepfwi_get_stats", "sepfwi_loop_status", "sepfwi_set_option", "sepfwi_get_option", "sepfwi_debug_field", "sepfwi_set_observed",
               "sepfwi_param_forward", "sepfwi_param_backward", "sepfwi_version", "sepfwi_device_count"):
         getattr(L, f).restype = C.c_int
     L.sepfwi_release_all.restype = None
@@ -110,7 +111,7 @@ def lib():
 
 EXPORTS = ["sepfwi_last_error", "sepfwi_version", "sepfwi_device_count", "sepfwi_cufd", "sepfwi_cufd_stream",
            "sepfwi_release_all", "sepfwi_invalidate_observed", "sepfwi_cpml_profiles", "sepfwi_stf_taper",
-           "sepfwi_shot_split", "sepfwi_get_stats", "sepfwi_set_option", "sepfwi_get_option", "sepfwi_debug_field",
+           "sepfwi_shot_split", "sepfwi_get_stats", "sepfwi_loop_status", "sepfwi_set_option", "sepfwi_get_option", "sepfwi_debug_field",
            "sepfwi_set_observed", "sepfwi_param_forward", "sepfwi_param_backward"]
 
 

@@ -226,6 +226,12 @@ class _FwiOps:
         _native.check(_native.lib().sepfwi_get_stats(str(para_fname).encode(), int(gpu_id), C.byref(st)))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
+    def loop_status(self, para_fname, gpu_id=0):
+        """"" while the session's backward passes run in the persistent loop, else why they do not (sepfwi_loop_status)."""
+        buf = C.create_string_buffer(512)
+        _native.check(_native.lib().sepfwi_loop_status(str(para_fname).encode(), int(gpu_id), buf, 512))
+        return buf.value.decode(errors="replace")
+
     def release(self):
         _native.lib().sepfwi_release_all()
 

@@ -214,6 +214,13 @@ def test_bench_spawns_its_own_ranks():
     nzp, nxp = [int(v) for v in re.search(r"padded (\d+)x(\d+)", two["config"]["workload"]).groups()][::-1]
     assert rc["bytes"] == 4 * (3 * nzp * nxp + 1)
     assert 0 < two["rank_ms_per_step"]["min"] <= two["rank_ms_per_step"]["max"]
+    # ... and that no rank silently fell back from the persistent loop: per-rank share of backward steps inside it, with the reason
+    # where a rank did not take it (two ranks share the card here: the loop's start rendezvous may legitimately say "GPU busy")
+    for line, n in ((one, 1), (two, 2)):
+        pl = line["persistent_loop"]
+        assert len(pl["share_of_bwd_steps_per_rank"]) == n and pl["share_of_bwd_steps_min"] == min(pl["share_of_bwd_steps_per_rank"])
+        for r, f in enumerate(pl["share_of_bwd_steps_per_rank"]):
+            assert 0.0 <= f <= 1.0 and (f == 1.0 or str(r) in pl["why_not"]), pl
     if torch.cuda.device_count() >= 2:
         rc = _run_bench(["--gpus", "2"])
         assert rc["n_gpus"] == 2 and rc["value"] > 0
@@ -234,6 +241,8 @@ def test_bench_rehearsal_of_the_driver_command_with_four_ranks():
     assert rc["ranks"] == 4 and rc["backend"] == "gloo" and rc["calls_per_rank"] == 2 and rc["bytes"] == 4 * (3 * 1088 * 2064 + 1)
     assert rc["allreduce_ms"] > 0 and rc["allreduce_ms_max"] >= rc["allreduce_ms"]
     assert 0 < r["rank_ms_per_step"]["min"] <= r["rank_ms_per_step"]["max"]
+    pl = r["persistent_loop"]      # four ranks on ONE card: whoever loses the start rendezvous says so, rank by rank
+    assert len(pl["share_of_bwd_steps_per_rank"]) == 4 and all((f == 1.0) or (str(k) in pl["why_not"]) for k, f in enumerate(pl["share_of_bwd_steps_per_rank"])), pl
 
 
 def _rccl_one_rank_worker(port, q):

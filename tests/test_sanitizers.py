@@ -54,3 +54,18 @@ def test_persistent_loop_tiling_under_asan_ubsan(tmp_path):
     for seed in (1, 2):
         out = subprocess.run([exe, str(seed), "300"], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_injection_plan_under_asan_ubsan(tmp_path):
+    """The host-built adjoint-source plan of the persistent loop's general receivers (csrc/inject_plan.cpp): for random scattered,
+    repeated, strided, vertical and directional channel sets, folding the residual per target cell and adding it through lookup /
+    lane mask / popcount leaves exactly what the channel-by-channel adds of res_injection_exx / _ezz (Src/utilities.cu:605-641) leave."""
+    exe = str(tmp_path / "inject_plan_check")
+    src = [os.path.join(ROOT, "tests", "native", "inject_plan_check.cpp"), os.path.join(ROOT, "sep-2023_amd", "csrc", "inject_plan.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-o", exe] + src)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    for seed in (1, 2):
+        out = subprocess.run([exe, str(seed), "400"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
