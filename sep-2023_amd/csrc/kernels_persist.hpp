@@ -43,7 +43,14 @@
 __device__ unsigned long long *g_pk_trace;
 constexpr int kTrTiles = 512, kTrPh0 = 200, kTrPh = 8, kTrSlots = 12;
 #endif
+#ifdef SEPFWI_PK_FAULT
+// Fault-injection build (tests/test_gpu_parity.py::test_loop_failure_path_reports_and_recovers; libsepfwi_fault.so): tile number
+// SEPFWI_PK_FAULT stops publishing its phases after the 40th, so that its neighbours run into the time limit inside a pass --
+// the one path of the loop that a healthy run never takes.  The limit is shortened to keep the test short.
+constexpr int kPersistSpinLimit = 1 << 14;
+#else
 constexpr int kPersistSpinLimit = 1 << 21;   // polls of ~1 us: about two seconds (never reached once the start rendezvous has passed)
+#endif
 constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 
 // registers sized for 8 waves per SIMD: two workgroups of 16 waves per CU
@@ -273,8 +280,11 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                 int old = 0;
                 if (lane == 0) old = atomicAdd(&edge_done, 1);
                 old = __builtin_amdgcn_readfirstlane(old);
-                if (old + 1 == nw * (local + 1) && lane == 0 && !nosync)
-                    __hip_atomic_store(my_flag, phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool publish = old + 1 == nw * (local + 1) && lane == 0 && !nosync;
+#ifdef SEPFWI_PK_FAULT
+                if (tile == (SEPFWI_PK_FAULT) && phase >= 40u) publish = false;
+#endif
+                if (publish) __hip_atomic_store(my_flag, phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 reported = true;
             };
             for (; w < base + nst; w = grab()) {

@@ -17,7 +17,10 @@ LIB_PATH = os.path.join(_ROOT, "libsepfwi.so")
 # structures) and the timing-only switches that the shipped library does not expose (include/sepfwi.h).  Used by scripts/ab_bench.py
 # and by the tests that prove every selectable kernel structure bit-identical; never by the operators unless asked to (use_variant).
 PROBES_LIB_PATH = os.path.join(_ROOT, "libsepfwi_probes.so")
-VARIANTS = {"default": (LIB_PATH, []), "probes": (PROBES_LIB_PATH, ["-DSEPFWI_PROBES"])}
+# ... and with -DSEPFWI_PK_FAULT=<tile>: a fault-injection build whose persistent loop stalls on purpose (one tile stops publishing), for
+# the one test that must see the loop's time-out path work (tests/test_gpu_parity.py::test_loop_failure_path_reports_and_recovers).
+FAULT_LIB_PATH = os.path.join(_ROOT, "libsepfwi_fault.so")
+VARIANTS = {"default": (LIB_PATH, []), "probes": (PROBES_LIB_PATH, ["-DSEPFWI_PROBES"]), "fault": (FAULT_LIB_PATH, ["-DSEPFWI_PK_FAULT=17"])}
 PUBLIC_OPTIONS = ("bwd_fuse", "batch", "img_every", "quiet_skip", "obs_cache_mb", "probe")
 SOURCES = ["kernels.hip", "param_maps.hip", "conditioning.hip", "session.cpp", "session_run.cpp", "session_persist.cpp", "session_batched.cpp", "obs_store.cpp", "host_checks.cpp", "persist_plan.cpp", "inject_plan.cpp", "config.cpp", "capi.cpp"]
 HEADERS = ["kernels.hpp", "kernels_device.hpp", "kernels_bodies.hpp", "kernels_quiet.hpp", "kernels_step.hpp", "kernels_persist.hpp", "kernels_aux.hpp", "param_maps.hpp", "conditioning.hpp", "device_common.hpp", "device_alloc.hpp", "obs_store.hpp", "host_checks.hpp", "persist_plan.hpp", "inject_plan.hpp", "errors.hpp", "hip_check.hpp", "session.hpp", "config.hpp", "fwi_types.hpp", "json_min.hpp",
