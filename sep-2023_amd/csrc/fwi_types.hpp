@@ -127,6 +127,15 @@ struct InjArgs {
     int ntgt, nseg;
 };
 
+// k_bwd_persist<.., MS = true>: several shots in one launch.  Shot k of the launch has its fields at s.fields + k state_stride, its
+// backward-pass arrays (memories, adjoint fields, accumulators) at + k bwd_stride, its boundary frames, residual, source trace and
+// source gradient likewise; its scalars are shots[k].
+struct MultiShot {
+    const ShotDev *shots;
+    size_t state_stride, bwd_stride, frame_stride, res_stride;  // floats
+    int nshot;
+};
+
 constexpr unsigned int kPersistGo = 1, kPersistAbortResidency = 2, kPersistAbortPlacement = 3;  // start rendezvous of k_bwd_persist
 
 // Argument block of the persistent backward time loop (k_bwd_persist), passed BY VALUE: pointers that arrive in the kernel-argument
@@ -152,6 +161,7 @@ struct PersistArgs {
     int lock;                // -DSEPFWI_PROBES builds, timing experiments only: phases interleaved (option pk_lock)
     int prio;                // 1: wave priorities interleave the CU's two workgroups (kernels.hip)
     InjArgs inj;             // k_bwd_persist<LMASK, true>: general receivers (else unused)
+    MultiShot ms;            // k_bwd_persist<LMASK, false, true>: the shots of the launch (else unused)
 };
 
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step

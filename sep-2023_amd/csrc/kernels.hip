@@ -231,28 +231,30 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
-static void (*persist_kernel(int lmask, bool ginj))(Grid, const PersistArgs) {
+static void (*persist_kernel(int lmask, bool ginj, bool ms))(Grid, const PersistArgs) {
+#define SEPFWI_PK(M) (ms ? k_bwd_persist<M, false, true> : ginj ? k_bwd_persist<M, true> : k_bwd_persist<M>)
     switch (lmask) {
-        case 0: return ginj ? k_bwd_persist<0, true> : k_bwd_persist<0>;
-        case 1: return ginj ? k_bwd_persist<1, true> : k_bwd_persist<1>;
-        case 3: return ginj ? k_bwd_persist<3, true> : k_bwd_persist<3>;
-        case 7: return ginj ? k_bwd_persist<7, true> : k_bwd_persist<7>;
-        case 15: return ginj ? k_bwd_persist<15, true> : k_bwd_persist<15>;
-        case 31: return ginj ? k_bwd_persist<31, true> : k_bwd_persist<31>;
+        case 0: return SEPFWI_PK(0);
+        case 1: return SEPFWI_PK(1);
+        case 3: return SEPFWI_PK(3);
+        case 7: return SEPFWI_PK(7);
+        case 15: return SEPFWI_PK(15);
+        case 31: return SEPFWI_PK(31);
         default: return nullptr;
     }
+#undef SEPFWI_PK
 }
 
 // 0, or why this grid cannot run the persistent loop (never launch a grid that would not be resident at once: its tiles wait for
 // each other): -1 no kernel instance for this LDS mask, -2 the LDS request is refused, -3 the occupancy query fails, -4 fewer
 // workgroups fit the device than the grid has.  Asked ONCE per configuration (Session::persist_ready); it also raises the kernel's
 // dynamic-LDS limit, which the launches rely on.
-int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes) {
+int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes, bool multi_shot) {
     int dev = 0, ncu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    for (int ginj = 0; ginj < 2; ginj++) {  // both instances of the configuration: fused line of channels / general receivers
-        const void *k = (const void *)persist_kernel(lmask, ginj != 0);
+    for (int ginj = 0; ginj < (multi_shot ? 1 : 2); ginj++) {  // single shot: both instances of the configuration (fused line of channels / general receivers)
+        const void *k = (const void *)persist_kernel(lmask, ginj != 0, multi_shot);
         if (!k) return -1;
         if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
         int per_cu = 0;
@@ -265,7 +267,7 @@ int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes) {
 int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
-    auto k = persist_kernel(lmask, args.inj.lookup != nullptr);
+    auto k = persist_kernel(lmask, args.inj.lookup != nullptr, args.ms.nshot > 0);
     if (!k) return -1;
 #ifdef SEPFWI_PK_TRACE
     {

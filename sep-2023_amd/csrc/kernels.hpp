@@ -75,7 +75,7 @@ void launch_bwd_b_batch(hipStream_t st, const Grid &g, const KernelOptions &o, c
                         size_t n, int it, float src_scale, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // persistent backward time loop (tiles: persist_plan.hpp).  persist_config_check: 0, or < 0 when this grid cannot be resident at once /
 // the LDS does not fit (once per configuration).  launch_bwd_persist: the launch of a checked configuration (0, or -1: no such kernel).
-int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes);
+int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes, bool multi_shot = false);
 int launch_bwd_persist(hipStream_t st, const Grid &g, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_add_inplace(hipStream_t st, float *a, const float *b, size_t n);

@@ -57,7 +57,12 @@ constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 // GINJ: the shot's receivers are not a fused horizontal line (scattered or strided channels, a vertical fibre, directional
 // sensitivities): the residual of the step, folded per target cell beforehand (k_inject_values), is added by the lane that owns the
 // cell right after its adjoint-velocity update -- res_injection_exx / _ezz (Src/utilities.cu:605-641) without a launch of its own.
-template <int LMASK, bool GINJ = false>
+// MS: ONE launch carries several shots through their backward passes (grids far below the headline's size, where a single shot cannot
+// feed 512 tiles: the reference's own experiments are 101 x 201 cells x 19 shots).  The tiles cut a VIRTUAL grid -- the shots of the
+// batch stacked row-wise -- so a row segment's descriptor also names its shot (bits 26..31); the shots' arrays lie at constant
+// strides (PersistArgs::ms), their scalars (source, line of channels) in the ShotDev table of the batched launches.  Everything else
+// -- phases, flags, LDS accumulators, the bodies -- is the single-shot loop's.
+template <int LMASK, bool GINJ = false, bool MS = false>
 __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
     extern __shared__ float lds_dyn[];
     __shared__ int next_item, edge_done, abort_flag, start_verdict, cu_slot_s;
@@ -132,16 +137,23 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
         return c;
     };
     // prologue: the tile's accumulators HBM -> LDS (they carry the sum over the shots of the call)
+    // (MS: the accumulators of the segment's own shot)
+    auto acc_arrays = [&](uint32_t d) {
+        if constexpr (MS) return acc_of(s.acc + (size_t)(d >> 26) * a.ms.bwd_stride, n);
+        else return acc.p;
+    };
     if constexpr (LMASK != 0) {
         for (int j = wave; j < nst; j += nw) {
-            const Cell c = cell_of(segs[j]);
+            const uint32_t d = segs[j];
+            const Cell c = cell_of(d);
+            const ImgAcc ap = acc_arrays(d);
             lds_float *cell = lbase + j * BX + lane;
             int r = 0;
-            if constexpr (LMASK & 1) cell[(r++) * acc.stride] = acc.p.lam[c.i];
-            if constexpr (LMASK & 2) cell[(r++) * acc.stride] = acc.p.mu[c.i];
-            if constexpr (LMASK & 4) cell[(r++) * acc.stride] = acc.p.xz[c.i];
-            if constexpr (LMASK & 8) cell[(r++) * acc.stride] = acc.p.a[c.i];
-            if constexpr (LMASK & 16) cell[(r++) * acc.stride] = acc.p.b[c.i];
+            if constexpr (LMASK & 1) cell[(r++) * acc.stride] = ap.lam[c.i];
+            if constexpr (LMASK & 2) cell[(r++) * acc.stride] = ap.mu[c.i];
+            if constexpr (LMASK & 4) cell[(r++) * acc.stride] = ap.xz[c.i];
+            if constexpr (LMASK & 8) cell[(r++) * acc.stride] = ap.a[c.i];
+            if constexpr (LMASK & 16) cell[(r++) * acc.stride] = ap.b[c.i];
         }
     }
     __syncthreads();
@@ -166,6 +178,40 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             const Cell c = cell_of(d);
             acc.cell = lbase + j * BX + lane;
             const bool xband = (d & kSegXband) != 0 && sync;  // wave-uniform
+            if constexpr (MS) {
+                // the segment's shot: its arrays at constant strides from the first shot's, its scalars from the table (scalar loads)
+                typedef const ShotDev __attribute__((address_space(4))) *shots_t;
+                const int sh = (int)(d >> 26);
+                const shots_t q = (shots_t)a.ms.shots + sh;
+                const size_t so = (size_t)sh * a.ms.state_stride, bo = (size_t)sh * a.ms.bwd_stride;
+                const Fields f1 = fields_of(s.fields + so, n), adj1 = fields_of(s.adj + bo, n);
+                const PmlMem m1 = mem_of(s.bmem + bo, n);
+                AccT<LMASK> acc1{acc_of(s.acc + bo, n), acc.cell, acc.stride};
+                float *frame1 = s.frame + (size_t)sh * a.ms.frame_stride + (size_t)it * 5 * (size_t)g.frame_len;
+                if (ph == 0) {
+                    if (xband) {
+                        velocity_body<false, AccT<LMASK>, MemAgent>(gs, c, f1, m1, md, pc, frame1, -1, -1, 0.0f, nullptr, adj1, acc1);
+                        stress_adj_body<MemAgent>(gs, c, adj1, m1, md, pc);
+                    } else {
+                        velocity_body<false>(gs, c, f1, m1, md, pc, frame1, -1, -1, 0.0f, nullptr, adj1, acc1);
+                        stress_adj_body(gs, c, adj1, m1, md, pc);
+                    }
+                } else {
+                    const int z_src = q->z_src, x_src = q->x_src, nrec1 = q->nrec;
+                    const float amp1 = __fmul_rn(__fmul_rn(a.src_scale, s.stf[(size_t)sh * (size_t)g.nSteps + it]), g.dt);
+                    const LineRec lr1{q->lr_z, q->lr_x0, q->lr_n, nullptr, nullptr, nullptr, s.res + (size_t)sh * a.ms.res_stride + (size_t)it * (size_t)nrec1};
+                    if (c.z == z_src && c.x == x_src)
+                        s.stf_grad[(size_t)sh * (size_t)g.nSteps + it] = -(adj1.szz[c.i] + q->src_rxz * adj1.sxx[c.i]) * g.dt;  // source_grad
+                    if (xband) {
+                        stress_body<false, false, AccT<LMASK>, MemAgent>(gs, c, f1, m1, md, pc, frame1, z_src, x_src, amp1, adj1, acc1, LineRec{});
+                        velocity_adj_body<MemAgent>(gs, c, adj1, m1, md, pc, lr1);
+                    } else {
+                        stress_body<false, false>(gs, c, f1, m1, md, pc, frame1, z_src, x_src, amp1, adj1, acc1, LineRec{});
+                        velocity_adj_body(gs, c, adj1, m1, md, pc, lr1);
+                    }
+                }
+                return;
+            }
             if (ph == 0) {
                 // phase A: reverse-time velocity (+ rho imaging, frame restore) + adjoint stress of the previous step
                 if (xband) {
@@ -313,14 +359,16 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
     // epilogue: LDS -> HBM
     if constexpr (LMASK != 0) {
         for (int j = wave; j < nst; j += nw) {
-            const Cell c = cell_of(segs[j]);
+            const uint32_t d = segs[j];
+            const Cell c = cell_of(d);
+            const ImgAcc ap = acc_arrays(d);
             lds_float *cell = lbase + j * BX + lane;
             int r = 0;
-            if constexpr (LMASK & 1) acc.p.lam[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 2) acc.p.mu[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 4) acc.p.xz[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 8) acc.p.a[c.i] = cell[(r++) * acc.stride];
-            if constexpr (LMASK & 16) acc.p.b[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 1) ap.lam[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 2) ap.mu[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 4) ap.xz[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 8) ap.a[c.i] = cell[(r++) * acc.stride];
+            if constexpr (LMASK & 16) ap.b[c.i] = cell[(r++) * acc.stride];
         }
     }
 }

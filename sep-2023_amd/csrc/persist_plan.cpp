@@ -26,7 +26,8 @@ std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w
             const int x0 = xs * 64, x1 = std::min(cost.nx, x0 + 64) - 1;
             const int in_layers = std::max(0, std::min(x1, cost.npml - 1) - x0 + 1) + std::max(0, x1 - std::max(x0, cost.nx - cost.npml) + 1);
             if (in_layers > 0) w = w * (in_layers == x1 - x0 + 1 ? cost.w_xpure : cost.w_xpml) / 100;
-            if (z < cost.npml || z > nzc - cost.npml - 1) w = w * cost.w_zpml / 100;
+            const int zl = cost.period > 0 ? z % cost.period : z, nzl = cost.period > 0 ? cost.period : nzc;
+            if (zl < cost.npml || zl > nzl - cost.npml - 1) w = w * cost.w_zpml / 100;
         }
         return std::max(1LL, w);
     };
@@ -101,6 +102,21 @@ std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w
         uint32_t *dst = p.seg.data() + (size_t)t * cap;
         std::copy(edge.begin(), edge.end(), dst);
         std::copy(inner.begin(), inner.end(), dst + edge.size());
+    }
+    return "";
+}
+
+std::string make_persist_plan_multishot(int nzc, int nshot, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first,
+                                        const PlanCost &cost) {
+    if (nshot < 1 || nshot > kPlanMaxShots) return "persist plan: more than " + std::to_string(kPlanMaxShots) + " shots in one launch";
+    if ((long long)nzc * nshot > 65535) return "persist plan: the stacked shots have more rows than the descriptor holds";
+    PlanCost c = cost;
+    c.period = nzc;
+    const std::string why = make_persist_plan(nzc * nshot, nseg, nwg, nband, strip_w, out, edge_first, c);
+    if (!why.empty()) return why;
+    for (uint32_t &d : out->seg) {
+        const uint32_t zv = d & 0xffffu;
+        d = (d & ~0xffffu) | (zv % (uint32_t)nzc) | ((zv / (uint32_t)nzc) << 26);
     }
     return "";
 }

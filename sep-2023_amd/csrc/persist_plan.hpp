@@ -50,8 +50,17 @@ struct PlanCost {
     int w_xpml = 100, w_xpure = 100, w_zpml = 100;  // percent
     const int *band_w = nullptr;     // [nband] percent, or null
     bool snake = true;               // strips walked top-down / bottom-up alternately (false: all top-down -- an experiment, -DSEPFWI_PROBES)
+    int period = 0;                  // > 0: the rows are `period`-row grids stacked on each other (several shots in one launch): the z layers repeat
 };
 std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true,
                               const PlanCost &cost = PlanCost());
+
+// Several shots in one launch (k_bwd_persist<.., MS>): the plan of the VIRTUAL grid of nshot grids of nzc rows stacked on each other
+// (make_persist_plan with nzc * nshot rows and cost.period = nzc; stencils never cross a shot's first or last two rows, so the
+// neighbour relations the plan finds there only over-synchronise), its descriptors rewritten to  row inside the shot | segment
+// column << 16 | flags | shot << 26.  Empty string, or why not (more than 64 shots, more rows than the descriptor holds).
+constexpr int kPlanMaxShots = 64;
+std::string make_persist_plan_multishot(int nzc, int nshot, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true,
+                                        const PlanCost &cost = PlanCost());
 
 }  // namespace sepfwi

@@ -208,13 +208,8 @@ Session::Session(const std::string &para_fname, int gpu_id, const std::string &p
 Session::~Session() {
     (void)hipSetDevice(gpu_id_);
     (void)hipDeviceSynchronize();
-    for (BLane &L : bl_) {
-        if (L.state) (void)hipFree(L.state);
-        if (L.bwd) (void)hipFree(L.bwd);
-        if (L.frame) (void)hipFree(L.frame);
-        if (L.syn) (void)hipFree(L.syn);
-        if (L.res) (void)hipFree(L.res);
-    }
+    for (float *p : {ba_.state, ba_.syn, ba_.res, ba_.frame, ba_.bwd})
+        if (p) (void)hipFree(p);
     if (d_shots_) (void)hipFree(d_shots_);
     if (d_stf_) (void)hipFree(d_stf_);
     for (XLane &L : xl_) {
@@ -226,11 +221,13 @@ Session::~Session() {
         if (L.join) (void)hipEventDestroy(L.join);
     }
     obs_.reset();
-    if (pk_.d_seg) (void)hipFree(pk_.d_seg);
-    if (pk_.d_hdr) (void)hipFree(pk_.d_hdr);
-    if (pk_.d_sync) (void)hipFree(pk_.d_sync);
-    if (pk_.d_stf) (void)hipFree(pk_.d_stf);
-    if (pk_.h_err) (void)hipHostFree(pk_.h_err);
+    for (Persist *k : {&pk_, &pk_ms_}) {
+        if (k->d_seg) (void)hipFree(k->d_seg);
+        if (k->d_hdr) (void)hipFree(k->d_hdr);
+        if (k->d_sync) (void)hipFree(k->d_sync);
+        if (k->d_stf) (void)hipFree(k->d_stf);
+        if (k->h_err) (void)hipHostFree(k->h_err);
+    }
     for (auto &kv : inj_) {
         InjDev &d = kv.second;
         (void)hipFree(d.lookup);
@@ -275,26 +272,37 @@ void Session::ensure_lanes(int n_lanes, bool with_frames) {
 
 // Batched mode: n_fwd lanes of forward state, the first n_bwd of them with backward state too; shot table and source rows
 // for n_shots shots.
+// Lanes of the batched schedule.  The lanes of one kind lie in ONE arena at a constant stride (the multi-shot persistent loop
+// addresses shot k of a launch as base + k stride, fwi_types.hpp MultiShot); an arena that is too small is replaced -- lanes carry
+// nothing from one call to the next.
 void Session::ensure_batch(int n_fwd, int n_bwd, bool with_frames, int n_shots) {
     const size_t n = cells_;
-    if ((int)bl_.size() < n_fwd) bl_.resize(n_fwd);
-    for (int k = 0; k < n_fwd; k++) {
+    auto regrow = [&](float *&arena, int &cap, int want, size_t per_lane) {
+        if (want <= cap) return;
+        if (arena) {
+            (void)hipFree(arena);
+            device_bytes_ -= (long long)((size_t)cap * per_lane * sizeof(float));
+        }
+        arena = nullptr;
+        cap = 0;
+        HIP_OK(dev_malloc((void **)&arena, (size_t)want * per_lane * sizeof(float)));
+        cap = want;
+        device_bytes_ += (long long)((size_t)want * per_lane * sizeof(float));
+    };
+    const size_t frame_lane = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len;
+    regrow(ba_.state, ba_.n_state, n_fwd, 13 * n);
+    regrow(ba_.syn, ba_.n_syn, n_fwd, 4 * data_len_);
+    regrow(ba_.res, ba_.n_res, n_fwd, data_len_);
+    if (with_frames) regrow(ba_.frame, ba_.n_frame, n_fwd, frame_lane);
+    regrow(ba_.bwd, ba_.n_bwd, n_bwd, 18 * n);
+    bl_.assign((size_t)std::max(ba_.n_state, 1), BLane{});
+    for (int k = 0; k < ba_.n_state; k++) {
         BLane &L = bl_[k];
-        if (!L.state) {
-            HIP_OK(dev_malloc((void **)&L.state, 13 * n * sizeof(float)));
-            HIP_OK(dev_malloc((void **)&L.syn, 4 * data_len_ * sizeof(float)));
-            HIP_OK(dev_malloc((void **)&L.res, data_len_ * sizeof(float)));
-            device_bytes_ += (long long)((13 * n + 5 * data_len_) * sizeof(float));
-        }
-        if (with_frames && !L.frame) {
-            const size_t fb = (size_t)par_.nSteps * 5 * (size_t)g_.frame_len * sizeof(float);
-            HIP_OK(dev_malloc((void **)&L.frame, fb));
-            device_bytes_ += (long long)fb;
-        }
-        if (k < n_bwd && !L.bwd) {
-            HIP_OK(dev_malloc((void **)&L.bwd, 18 * n * sizeof(float)));
-            device_bytes_ += (long long)(18 * n * sizeof(float));
-        }
+        L.state = ba_.state + (size_t)k * 13 * n;
+        L.syn = ba_.syn + (size_t)k * 4 * data_len_;
+        L.res = ba_.res + (size_t)k * data_len_;
+        L.frame = k < ba_.n_frame ? ba_.frame + (size_t)k * frame_lane : nullptr;
+        L.bwd = k < ba_.n_bwd ? ba_.bwd + (size_t)k * 18 * n : nullptr;
     }
     if (n_shots > shots_cap_) {
         if (d_shots_) (void)hipFree(d_shots_);

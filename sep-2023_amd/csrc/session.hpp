@@ -109,11 +109,15 @@ class Session {
     void backward_step(Call &c, const ShotCtx &x, const BwdLane &L, int it);
     void backward(Call &c, const ShotCtx &x);
     // the same pass as ONE persistent launch (option bwd_fuse = 4; kernels.hip k_bwd_persist)
+    struct Persist;
     bool persist_ready(const Call &c, const ShotCtx &x);
+    bool persist_prepare(Persist &k, const KernelOptions &opt, int nshots);
     bool backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L);
+    bool batched_backward_persistent(Call &c, const std::vector<ShotDev> &tab, int first, int nbb);
+    bool persist_launch(Persist &k, Call &c, PersistArgs &a, hipStream_t st);
     void persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, InjArgs *out);
-    void persist_demote(const std::string &why, int retry_in);
-    void persist_check_pass();
+    void persist_demote(Persist &k, const std::string &why, int retry_in);
+    void persist_check_pass(Persist &k);
     hipEvent_t *probe_pair(Call &c, int it);
     void collect_probes(Call &c);
     // the two schedules of a call's shots
@@ -162,6 +166,10 @@ class Session {
         float *state = nullptr, *bwd = nullptr, *frame = nullptr, *syn = nullptr, *res = nullptr;
     };
     std::vector<BLane> bl_;
+    struct BatchArenas {  // the lanes of one kind at a constant stride (ensure_batch)
+        float *state = nullptr, *syn = nullptr, *res = nullptr, *frame = nullptr, *bwd = nullptr;
+        int n_state = 0, n_syn = 0, n_res = 0, n_frame = 0, n_bwd = 0;
+    } ba_;
     ShotDev *d_shots_ = nullptr;
     int shots_cap_ = 0;
     float *d_stf_ = nullptr;
@@ -194,12 +202,12 @@ class Session {
         unsigned int *d_sync = nullptr;  // [nwg x 32 flag words | 8 band XCC ids | arrived | err]
         float *d_stf = nullptr;
         int *h_err = nullptr;            // pinned
-        int nwg = 0, threads = 0, lmask = 0, lmask_req = -1, wpc = 0, strip_w = 0, order = -1, wx = -1, wxp = -1, wz = -1, snake = -1;
+        int nwg = 0, threads = 0, lmask = 0, lmask_req = -1, wpc = 0, strip_w = 0, order = -1, wx = -1, wxp = -1, wz = -1, snake = -1, nshots = 0;
         size_t lds_bytes = 0;
         int state = -1;                  // -1 not examined for this configuration, 0 the two-launch step is used, 1 ready
         std::string why;                 // when state == 0
         int retry_in = 0, aborts = 0;    // passes until the loop is tried again after a start rendezvous that failed; how often it did
-    } pk_;
+    } pk_, pk_ms_;  // one shot per launch (stream schedule) / the shots of a backward sub-batch in one launch (batched schedule)
     // adjoint-source injection inside the loop for shots whose receivers are not a fused line: the plan of each such shot (device
     // copies, built on first use) and the pass's residual folded per target cell [nSteps][ntgt]
     struct InjDev {

@@ -136,9 +136,16 @@ void Session::batched_backward(Call &c, const std::vector<ShotDev> &tab, int fir
     int nsb = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nbb));  // sub-batches on streams of their own, as in the forward loop
     for (int k = 0; k < nbb; k++)
         if (tab[first + k].lr_n == 0) nsb = 1;  // (k_inject runs on the call's stream)
+    // the whole sub-batch as ONE persistent launch (the multi-shot loop, session_persist.cpp) where every shot's channels are a fused
+    // line (or absent) and the stacked grids feed the loop's tiles; else -- or when its start rendezvous says the grid is not resident
+    // at once, which leaves everything untouched -- the per-step launches below
+    bool lines = opt.line_fuse != 0;
+    for (int k = 0; k < nbb; k++) lines = lines && (tab[first + k].nrec == 0 || tab[first + k].lr_n > 0);
+    const bool looped = lines && persist_prepare(pk_ms_, opt, nbb) && batched_backward_persistent(c, tab, first, nbb);
     hipStream_t sub[kMaxLanes] = {};
+    if (looped) nsb = 1;
     batch_streams(st, nsb, sub);
-    for (int it = nSteps - 2; it >= 0; it--) {
+    for (int it = nSteps - 2; it >= 0 && !looped; it--) {
         hipEvent_t *ev = probe_pair(c, it);
         Grid gs = g;
         if (opt.img_every > 1) gs.dt_img = (it % opt.img_every == 0) ? (float)opt.img_every * g.dt : 0.0f;
@@ -165,6 +172,7 @@ void Session::batched_backward(Call &c, const std::vector<ShotDev> &tab, int fir
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     bwd_ms_ += ms;
+    if (looped) persist_check_pass(pk_ms_);
 }
 
 void Session::run_batched(Call &c, int Bf, int Bb) {

@@ -33,16 +33,21 @@ static std::string persist_device(int gpu_id, int *ncu, size_t *lds_cu, int *nba
 // is resident at once (the GPU may be shared) and every band sits on one XCD is decided by the start rendezvous of each pass
 // (backward_persistent): a pass that does not start leaves everything untouched and runs as per-step launches.
 bool Session::persist_ready(const Call &c, const ShotCtx &x) {
-    const KernelOptions &opt = c.opt;
-    if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
     (void)x;  // every receiver geometry takes the loop: a fused line of channels inside the bodies, anything else through persist_inject
-    Persist &k = pk_;
-    if (k.state >= 0 && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order && k.wx == opt.pk_wx &&
-        k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask && k.snake == opt.pk_snake) {
+    return persist_prepare(pk_, c.opt, 1);
+}
+
+// nshots = 1: the loop over ONE shot's grid (stream schedule).  nshots > 1: the multi-shot loop of the batched schedule -- the tiles
+// cut the nshots grids stacked on each other (persist_plan.hpp make_persist_plan_multishot).
+bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) {
+    if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
+    if (k.state >= 0 && k.nshots == nshots && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order &&
+        k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask && k.snake == opt.pk_snake) {
         if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
         return k.state == 1;
     }
     k.state = 0;
+    k.nshots = nshots;
     k.wpc = opt.pk_wpc;
     k.strip_w = opt.pk_px;
     k.lmask_req = opt.pk_lmask;
@@ -58,7 +63,7 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     if (!k.why.empty()) return false;
     const int nseg = (g_.nx + 63) / 64;
     k.nwg = (ncu / nband) * nband * opt.pk_wpc;
-    if (k.nwg <= 0 || (long long)g_.nzc * nseg < 4LL * k.nwg) {  // tiles of a handful of segments: the per-step launches (batched) are the better form
+    if (k.nwg <= 0 || (long long)g_.nzc * nshots * nseg < 4LL * k.nwg) {  // tiles of a handful of segments: the per-step launches (batched) are the better form
         k.why = "grid too small for " + std::to_string(k.nwg) + " tiles";
         return false;
     }
@@ -69,7 +74,9 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
     cost.w_xpure = opt.pk_wxp;
     cost.w_zpml = opt.pk_wz;
     cost.snake = opt.pk_snake != 0;
-    k.why = make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
+    const bool multi = &k == &pk_ms_;  // the batched schedule's loop: the multi-shot kernel instance, also for a sub-batch of one
+    k.why = multi ? make_persist_plan_multishot(g_.nzc, nshots, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost)
+                       : make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
     if (!k.why.empty()) return false;
     // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a, b in that order)
     const size_t per_wg = lds_cu / (size_t)opt.pk_wpc - 256;
@@ -88,7 +95,7 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
         k.why = "LDS accumulators do not fit";
         return false;
     }
-    const int rc = persist_config_check(k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
+    const int rc = persist_config_check(k.nwg, k.threads, k.lmask, k.lds_bytes + 64, multi);
     if (rc != 0) {
         static const char *const kWhy[] = {"", "no kernel instance for this LDS mask", "the LDS request is refused", "the occupancy query failed",
                                            "fewer workgroups fit the device than the grid has"};
@@ -160,16 +167,17 @@ void Session::persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, In
 
 std::string Session::loop_status() {
     std::lock_guard<std::mutex> lock(mu_);
-    if (pk_.state < 0) return "not considered yet (no gradient call, the batched schedule, or bwd_fuse != 4)";
-    return pk_.state == 1 ? std::string() : pk_.why;
+    const Persist &k = last_batched_ ? pk_ms_ : pk_;  // the schedule of the last call: multi-shot loop (batched) or one loop per shot (streams)
+    if (k.state < 0) return "not considered yet (no gradient call, bwd_fuse != 4, or shots whose channels are not fused lines in a batched call)";
+    return k.state == 1 ? std::string() : k.why;
 }
 
 // The loop is not used for this pass (and, unless `retry_in` says otherwise, for the rest of the session): say so once.
-void Session::persist_demote(const std::string &why, int retry_in) {
-    pk_.state = 0;
-    pk_.why = why;
-    pk_.retry_in = retry_in;
-    if (pk_.aborts++ == 0) fprintf(stderr, "sepfwi: persistent backward loop not started (%s); this pass runs as per-step launches\n", why.c_str());
+void Session::persist_demote(Persist &k, const std::string &why, int retry_in) {
+    k.state = 0;
+    k.why = why;
+    k.retry_in = retry_in;
+    if (k.aborts++ == 0) fprintf(stderr, "sepfwi: persistent backward loop not started (%s); this pass runs as per-step launches\n", why.c_str());
 }
 
 // One shot's backward pass as one launch.  Returns false when the loop did not run -- the launch was refused, or the start
@@ -179,10 +187,6 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     Persist &k = pk_;
     const int nSteps = par_.nSteps;
     hipStream_t st = L.s;
-    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
-    int *err = (int *)(band_xcc + 10);
-    HIP_OK(hipMemsetAsync(k.d_sync, 0, ((size_t)k.nwg * 32 + 16) * sizeof(unsigned int), st));
-    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
     HIP_OK(hipMemcpyAsync(k.d_stf, x.stf_s, (size_t)nSteps * sizeof(float), hipMemcpyHostToDevice, st));
     PersistArgs a{};
     ShotDev &d = a.s;
@@ -201,6 +205,48 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     d.lr_n = x.line.n;
     d.nrec = x.nrec;
     d.src_rxz = (float)x.sh->src_rxz;
+    persist_inject(c, x, st, &a.inj);
+    if (!persist_launch(k, c, a, st)) return false;
+    persist_steps_ += (long long)(nSteps - 1);
+    return true;
+}
+
+// Several shots' backward passes as one launch (batched schedule; shots tab[first .. first + nbb) in backward lanes 0 .. nbb-1).
+// Same contract as backward_persistent.  The shots' arrays must lie at constant strides (ensure_batch's arenas) -- checked here,
+// not assumed -- and their channels must be fused lines (or absent).
+bool Session::batched_backward_persistent(Call &c, const std::vector<ShotDev> &tab, int first, int nbb) {
+    Persist &k = pk_ms_;
+    const int nSteps = par_.nSteps;
+    PersistArgs a{};
+    a.s = tab[first];
+    MultiShot &m = a.ms;
+    m.shots = d_shots_ + first;
+    m.nshot = nbb;
+    if (nbb > 1) {
+        m.state_stride = (size_t)(tab[first + 1].fields - tab[first].fields);
+        m.bwd_stride = (size_t)(tab[first + 1].bmem - tab[first].bmem);
+        m.frame_stride = (size_t)(tab[first + 1].frame - tab[first].frame);
+        m.res_stride = (size_t)(tab[first + 1].res - tab[first].res);
+    }
+    for (int q = 0; q < nbb; q++) {
+        const ShotDev &d = tab[first + q], &d0 = tab[first];
+        const bool ok = d.fields == d0.fields + q * m.state_stride && d.bmem == d0.bmem + q * m.bwd_stride && d.adj == d0.adj + q * m.bwd_stride &&
+                        d.acc == d0.acc + q * m.bwd_stride && d.frame == d0.frame + q * m.frame_stride && d.res == d0.res + q * m.res_stride &&
+                        d.stf == d0.stf + (size_t)q * nSteps && d.stf_grad == d0.stf_grad + (size_t)q * nSteps;
+        if (!ok) throw std::logic_error("multi-shot loop: the batch lanes do not lie at constant strides");
+    }
+    if (!persist_launch(k, c, a, c.st)) return false;
+    persist_steps_ += (long long)nbb * (nSteps - 1);
+    return true;
+}
+
+// The launch of a prepared configuration and its start verdict (shared by the single- and the multi-shot loop).
+bool Session::persist_launch(Persist &k, Call &c, PersistArgs &a, hipStream_t st) {
+    const int nSteps = par_.nSteps;
+    unsigned int *band_xcc = k.d_sync + (size_t)k.nwg * 32;
+    int *err = (int *)(band_xcc + 10);
+    HIP_OK(hipMemsetAsync(k.d_sync, 0, ((size_t)k.nwg * 32 + 16) * sizeof(unsigned int), st));
+    HIP_OK(hipMemsetAsync(band_xcc, 0xff, 8 * sizeof(unsigned int), st));
     a.media = md_.lam;
     a.cz = pc_.a_z;
     a.n = cells_;
@@ -220,11 +266,10 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     a.nosync = c.opt.pk_nosync;
     a.lock = c.opt.pk_lock;
     a.prio = c.opt.pk_prio;
-    persist_inject(c, x, st, &a.inj);
     const int rc = launch_bwd_persist(st, g_, c.opt, a, k.nwg, k.threads, k.lmask, k.lds_bytes + 64);
-    if (rc != 0 || hipPeekAtLastError() != hipSuccess) {  // refused before anything ran: the two-launch step from now on
+    if (rc != 0 || hipPeekAtLastError() != hipSuccess) {  // refused before anything ran: the per-step launches from now on
         const hipError_t e = hipGetLastError();
-        persist_demote("the launch was refused (code " + std::to_string(rc) + (e != hipSuccess ? std::string(", ") + hipGetErrorString(e) : std::string()) + ")", 0);
+        persist_demote(k, "the launch was refused (code " + std::to_string(rc) + (e != hipSuccess ? std::string(", ") + hipGetErrorString(e) : std::string()) + ")", 0);
         return false;
     }
     launches_++;
@@ -234,24 +279,23 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     if (k.h_err[1] != (int)kPersistGo) {  // the loop did not start: this pass, and the session from now on, as per-step launches
         const bool busy = k.h_err[1] != (int)kPersistAbortPlacement;
         // transient contention: another try after 16 passes, three times at most
-        persist_demote(busy ? "the grid was not resident at once (GPU busy, or the configuration does not fit)" : "workgroups of one band run on several XCDs",
+        persist_demote(k, busy ? "the grid was not resident at once (GPU busy, or the configuration does not fit)" : "workgroups of one band run on several XCDs",
                        busy && k.aborts < 3 ? 16 : 0);
         return false;
     }
-    persist_steps_ += (long long)(nSteps - 1);
     return true;
 }
 
 // After a pass that ran in the loop: a wait inside the pass timed out (a tile's neighbour never published)?  The results are
 // discarded, the session goes back to the two-launch step and the call fails with where the tiles stood (the reference: exit(1),
 // Src/utilities.h:28-36).
-void Session::persist_check_pass() {
-    if (pk_.h_err[0] == 0) return;
-    std::vector<unsigned int> fl((size_t)pk_.nwg * 32);  // flags[tile] = phases whose edge part is complete
-    HIP_OK(hipMemcpy(fl.data(), pk_.d_sync, fl.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+void Session::persist_check_pass(Persist &k) {
+    if (k.h_err[0] == 0) return;
+    std::vector<unsigned int> fl((size_t)k.nwg * 32);  // flags[tile] = phases whose edge part is complete
+    HIP_OK(hipMemcpy(fl.data(), k.d_sync, fl.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
     unsigned int lo = ~0u, hi = 0;
     int t_lo = 0, never = 0;
-    for (int t = 0; t < pk_.nwg; t++) {
+    for (int t = 0; t < k.nwg; t++) {
         const unsigned int v = fl[(size_t)t * 32];
         if (v < lo) {
             lo = v;
@@ -260,11 +304,11 @@ void Session::persist_check_pass() {
         hi = std::max(hi, v);
         never += v == 0;
     }
-    pk_.state = 0;
-    pk_.why = "a pass failed";
+    k.state = 0;
+    k.why = "a pass failed";
     throw HipError(std::string("persistent backward loop: a tile waited for its neighbour beyond the time limit") + " (results discarded; tiles reached phases " +
                    std::to_string(lo) + " ... " + std::to_string(hi) + " of " + std::to_string(2 * (par_.nSteps - 1)) + ", slowest tile " + std::to_string(t_lo) + ", " +
-                   std::to_string(never) + " of " + std::to_string(pk_.nwg) + " never published)");
+                   std::to_string(never) + " of " + std::to_string(k.nwg) + " never published)");
 }
 
 }  // namespace sepfwi

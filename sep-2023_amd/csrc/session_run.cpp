@@ -356,7 +356,7 @@ void Session::backward(Call &c, const ShotCtx &x) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     bwd_ms_ += ms;
-    if (looped) persist_check_pass();
+    if (looped) persist_check_pass(pk_);
 }
 
 // ---- stream schedule: up to fwd_lanes forward passes side by side (their kernel-boundary gaps and tails fill each other:

@@ -81,6 +81,35 @@ static int check(int nzc, int nseg, int nwg, int nband, int sw, const PlanCost *
     return 0;
 }
 
+// Several shots in one launch: every (shot, row, segment column) owned exactly once, descriptors within range, tile sizes as the
+// plan of the stacked grid gave them (make_persist_plan_multishot only rewrites the descriptors).
+static int check_multishot(int nzc, int nshot, int nseg, int nwg, int nband, int sw) {
+    PersistPlan p, q;
+    PlanCost pc;
+    pc.nx = nseg * 64 - 7;
+    pc.npml = std::min(10, nzc / 3);
+    pc.w_xpml = pc.w_xpure = 150;
+    pc.w_zpml = 115;
+    const std::string why = make_persist_plan_multishot(nzc, nshot, nseg, nwg, nband, sw, &p, true, pc);
+    if (!why.empty()) return (why.find("neighbours") != std::string::npos || why.find("without") != std::string::npos) ? 2 : -1;
+    pc.period = nzc;
+    if (!make_persist_plan(nzc * nshot, nseg, nwg, nband, sw, &q, true, pc).empty()) return 20;
+    std::vector<int> seen((size_t)nzc * nshot * nseg, 0);
+    for (int t = 0; t < nwg; t++) {
+        if (p.hdr[t].n_seg != q.hdr[t].n_seg || p.hdr[t].n_edge != q.hdr[t].n_edge || p.hdr[t].n_nb != q.hdr[t].n_nb) return 21;
+        for (int j = 0; j < p.hdr[t].n_seg; j++) {
+            const uint32_t d = p.seg[(size_t)t * p.cap + j], dv = q.seg[(size_t)t * q.cap + j];
+            const int z = (int)(d & 0xffffu), xs = (int)((d >> 16) & 0xffu), sh = (int)(d >> 26);
+            if (z >= nzc || xs >= nseg || sh >= nshot) return 22;
+            if ((int)(dv & 0xffffu) != sh * nzc + z || ((d ^ dv) & 0x03ff0000u) != 0u) return 23;  // same virtual row, same column and flags
+            seen[((size_t)sh * nzc + z) * nseg + xs]++;
+        }
+    }
+    for (int v : seen)
+        if (v != 1) return 24;
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const unsigned seed = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
     const int n = argc > 2 ? atoi(argv[2]) : 200;
@@ -110,6 +139,15 @@ int main(int argc, char **argv) {
         else if (rc == 2) refused++;
         else { printf("FAIL nzc %d nseg %d nwg %d nband %d strip %d: %d\n", nzc, nseg, nwg, nband, sw, rc); return 1; }
     }
+    // the reference's own experiments: 19 shots of 165 rows x 5 segment columns in one launch; and random stacks
+    rc = check_multishot(165, 19, 5, 512, 8, 3);
+    if (rc != 0) { printf("FAIL notebook-sized multi-shot plan: %d\n", rc); return 1; }
+    for (int it = 0; it < n / 4; it++) {
+        const int nzc = 8 + (int)(rng() % 300), nshot = 1 + (int)(rng() % 40), nseg = 1 + (int)(rng() % 12), per = 1 + (int)(rng() % 64), sw = 1 + (int)(rng() % 5);
+        rc = check_multishot(nzc, nshot, nseg, 8 * per, 8, sw);
+        if (rc != 0 && rc != 2) { printf("FAIL multi-shot nzc %d nshot %d nseg %d nwg %d strip %d: %d\n", nzc, nshot, nseg, 8 * per, sw, rc); return 1; }
+    }
+    if (check_multishot(100, 65, 4, 64, 8, 2) != -1 || check_multishot(3000, 30, 4, 64, 8, 2) != -1) { printf("FAIL: too many shots / rows accepted\n"); return 1; }
     if (check(70000, 3, 8, 8, 1) != -1 || check(10, 300, 8, 8, 1) != -1 || check(10, 10, 9, 8, 1) != -1) { printf("FAIL: bad arguments accepted\n"); return 1; }
     printf("OK %d plans checked, %d refused for more than %d neighbours\n", ok, refused, kPlanMaxNb);
     return 0;
