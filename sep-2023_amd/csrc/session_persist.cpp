@@ -63,7 +63,10 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
     if (!k.why.empty()) return false;
     const int nseg = (g_.nx + 63) / 64;
     k.nwg = (ncu / nband) * nband * opt.pk_wpc;
-    if (k.nwg <= 0 || (long long)g_.nzc * nshots * nseg < 4LL * k.nwg) {  // tiles of a handful of segments: the per-step launches (batched) are the better form
+    const bool multi = &k == &pk_ms_;  // the batched schedule's loop: the multi-shot kernel instance, also for a sub-batch of one
+    // One shot per launch: tiles of a handful of row segments lose to the batched per-step launches (which that schedule would have
+    // chosen).  The batched schedule itself: any sub-batch that gives every tile work (remainders of one or two small shots included).
+    if (k.nwg <= 0 || (long long)g_.nzc * nshots * nseg < (multi ? 3LL * k.nwg / 2 : 4LL * k.nwg)) {
         k.why = "grid too small for " + std::to_string(k.nwg) + " tiles";
         return false;
     }
@@ -74,7 +77,6 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
     cost.w_xpure = opt.pk_wxp;
     cost.w_zpml = opt.pk_wz;
     cost.snake = opt.pk_snake != 0;
-    const bool multi = &k == &pk_ms_;  // the batched schedule's loop: the multi-shot kernel instance, also for a sub-batch of one
     k.why = multi ? make_persist_plan_multishot(g_.nzc, nshots, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost)
                        : make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
     if (!k.why.empty()) return false;
