@@ -80,10 +80,13 @@ int sepfwi_cufd(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_D
                 const float *stf, int calc_id, int gpu_id, int group_size, const int *shot_ids,
                 const char *para_fname);
 
-/* Same as sepfwi_cufd, but all launches go to `hip_stream` (a hipStream_t, may be NULL) and the call
- * returns without a final device synchronisation when `async` != 0 and every output pointer is a
- * device pointer (misfit, gradients); the caller then synchronises its stream before it reads them
- * (tests/test_gpu_parity.py::test_c_abi_on_a_caller_stream_without_final_synchronisation). */
+/* Same as sepfwi_cufd, but all launches go to `hip_stream` (a hipStream_t, may be NULL), and with `async` != 0 and every output
+ * pointer (misfit, gradients) a device pointer the call does not end with a device synchronisation: the outputs are complete when the
+ * work queued on the stream is -- the caller synchronises its stream before reading them
+ * (tests/test_gpu_parity.py::test_c_abi_on_a_caller_stream_without_final_synchronisation).  `async` is NOT a promise that the host
+ * returns early: the call synchronises the stream internally between the passes of a shot (to form the misfit on the host side of
+ * the forward pass, and once per backward pass to learn whether the persistent loop's grid started -- a pass that does not start must
+ * be re-issued as per-step launches), so it returns when all but the final gradient kernels have run. */
 int sepfwi_cufd_stream(float *misfit, float *grad_Lambda, float *grad_Mu, float *grad_Den,
                        float *grad_stf, const float *Lambda, const float *Mu, const float *Den,
                        const float *stf, int calc_id, int gpu_id, int group_size,

@@ -102,6 +102,8 @@ const OptField kOptFields[] = {
     // distance D in row segments by which phase B trails phase A, 0x100 alternate walk direction per time step, 0x200 no barrier per step);
     // pk_snake 0: every strip of the tiling is walked top-down
     {"pk_nosync", &KernelOptions::pk_nosync, 0, 1}, {"pk_lock", &KernelOptions::pk_lock, 0, 0x3ff}, {"pk_snake", &KernelOptions::pk_snake, 0, 1},
+    // an experiment that lost (EXPERIMENTS #48): the batched schedule's backward sub-batches as ONE multi-shot persistent launch
+    {"pk_ms", &KernelOptions::pk_ms, 0, 1},
 #endif
 };
 }  // namespace
@@ -232,7 +234,11 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
 }
 
 static void (*persist_kernel(int lmask, bool ginj, bool ms))(Grid, const PersistArgs) {
+#ifdef SEPFWI_PROBES  // the multi-shot instances exist in the probe build only: measured slower than the per-step batched launches (EXPERIMENTS #48)
 #define SEPFWI_PK(M) (ms ? k_bwd_persist<M, false, true> : ginj ? k_bwd_persist<M, true> : k_bwd_persist<M>)
+#else
+#define SEPFWI_PK(M) (ms ? nullptr : ginj ? k_bwd_persist<M, true> : k_bwd_persist<M>)
+#endif
     switch (lmask) {
         case 0: return SEPFWI_PK(0);
         case 1: return SEPFWI_PK(1);

@@ -136,10 +136,10 @@ void Session::batched_backward(Call &c, const std::vector<ShotDev> &tab, int fir
     int nsb = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nbb));  // sub-batches on streams of their own, as in the forward loop
     for (int k = 0; k < nbb; k++)
         if (tab[first + k].lr_n == 0) nsb = 1;  // (k_inject runs on the call's stream)
-    // the whole sub-batch as ONE persistent launch (the multi-shot loop, session_persist.cpp) where every shot's channels are a fused
-    // line (or absent) and the stacked grids feed the loop's tiles; else -- or when its start rendezvous says the grid is not resident
-    // at once, which leaves everything untouched -- the per-step launches below
-    bool lines = opt.line_fuse != 0;
+    // An experiment that lost, kept in the -DSEPFWI_PROBES build (option pk_ms; profiles/EXPERIMENTS.md #48): the whole sub-batch as ONE
+    // persistent launch (the multi-shot loop, session_persist.cpp) where every shot's channels are a fused line (or absent).  On every
+    // grid that takes the batched schedule the per-step launches below are faster, also against the loop without any synchronisation.
+    bool lines = opt.pk_ms != 0 && opt.line_fuse != 0;
     for (int k = 0; k < nbb; k++) lines = lines && (tab[first + k].nrec == 0 || tab[first + k].lr_n > 0);
     const bool looped = lines && persist_prepare(pk_ms_, opt, nbb) && batched_backward_persistent(c, tab, first, nbb);
     hipStream_t sub[kMaxLanes] = {};
