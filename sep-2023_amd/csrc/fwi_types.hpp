@@ -136,6 +136,13 @@ struct MultiShot {
     int nshot;
 };
 
+// k_bwd_persist<.., QS = true>: quiet row segments inside the loop (option quiet_skip).
+struct QuietArgs {
+    const unsigned int *maps;       // the shot's forward maps as the forward pass left them: velocities at +0, stresses at +Grid::qn
+    const unsigned long long *nbr;  // [tiles][cap]: per row segment the positions IN THE TILE of the six row segments its stencils reach
+                                    // (rows z-2, z-1, z+1, z+2; columns xs-1, xs+1), one byte each: 0xff none (outside the grid), 0xfe another tile's
+};
+
 constexpr unsigned int kPersistGo = 1, kPersistAbortResidency = 2, kPersistAbortPlacement = 3;  // start rendezvous of k_bwd_persist
 
 // Argument block of the persistent backward time loop (k_bwd_persist), passed BY VALUE: pointers that arrive in the kernel-argument
@@ -162,6 +169,7 @@ struct PersistArgs {
     int prio;                // 1: wave priorities interleave the CU's two workgroups (kernels.hip)
     InjArgs inj;             // k_bwd_persist<LMASK, true>: general receivers (else unused)
     MultiShot ms;            // k_bwd_persist<LMASK, false, true>: the shots of the launch (else unused)
+    QuietArgs q;             // k_bwd_persist<LMASK, false, false, true>: quiet row segments (else unused)
 };
 
 struct Frame {  // boundary-saving storage, one block of 5*frame_len floats per time step

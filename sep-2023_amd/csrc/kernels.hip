@@ -233,11 +233,12 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
                            stf_grad_it, (lr.z << 16) | lr.x0, lr.n, lr.res);
 }
 
-static void (*persist_kernel(int lmask, bool ginj, bool ms))(Grid, const PersistArgs) {
+// kind: 0 fused line of channels (or none), 1 general receivers (GINJ), 2 several shots per launch (MS), 3 quiet row segments (QS)
+static void (*persist_kernel(int lmask, int kind))(Grid, const PersistArgs) {
 #ifdef SEPFWI_PROBES  // the multi-shot instances exist in the probe build only: measured slower than the per-step batched launches (EXPERIMENTS #48)
-#define SEPFWI_PK(M) (ms ? k_bwd_persist<M, false, true> : ginj ? k_bwd_persist<M, true> : k_bwd_persist<M>)
+#define SEPFWI_PK(M) (kind == 2 ? k_bwd_persist<M, false, true> : kind == 3 ? k_bwd_persist<M, false, false, true> : kind == 1 ? k_bwd_persist<M, true> : k_bwd_persist<M>)
 #else
-#define SEPFWI_PK(M) (ms ? nullptr : ginj ? k_bwd_persist<M, true> : k_bwd_persist<M>)
+#define SEPFWI_PK(M) (kind == 2 ? nullptr : kind == 3 ? k_bwd_persist<M, false, false, true> : kind == 1 ? k_bwd_persist<M, true> : k_bwd_persist<M>)
 #endif
     switch (lmask) {
         case 0: return SEPFWI_PK(0);
@@ -259,13 +260,15 @@ int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes, bool
     int dev = 0, ncu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    for (int ginj = 0; ginj < (multi_shot ? 1 : 2); ginj++) {  // single shot: both instances of the configuration (fused line of channels / general receivers)
-        const void *k = (const void *)persist_kernel(lmask, ginj != 0, multi_shot);
+    for (int kind : {0, 1, 3}) {  // single shot: every instance of the configuration (fused line of channels / general receivers / quiet segments)
+        if (multi_shot) kind = 2;
+        const void *k = (const void *)persist_kernel(lmask, kind);
         if (!k) return -1;
         if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds_bytes) != hipSuccess) return -3;
         if (per_cu * ncu < nwg) return -4;
+        if (multi_shot) break;
     }
     return 0;
 }
@@ -273,7 +276,7 @@ int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes, bool
 int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
-    auto k = persist_kernel(lmask, args.inj.lookup != nullptr, args.ms.nshot > 0);
+    auto k = persist_kernel(lmask, args.ms.nshot > 0 ? 2 : args.q.maps != nullptr ? 3 : args.inj.lookup != nullptr ? 1 : 0);
     if (!k) return -1;
 #ifdef SEPFWI_PK_TRACE
     {

@@ -52,6 +52,7 @@ constexpr int kPersistSpinLimit = 1 << 14;
 constexpr int kPersistSpinLimit = 1 << 21;   // polls of ~1 us: about two seconds (never reached once the start rendezvous has passed)
 #endif
 constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
+constexpr unsigned int kFlagPhase = 0x0fffffffu;  // a tile's flag word: phases completed (low 28 bits) | QS: summary of its edge segments (top 4)
 
 // registers sized for 8 waves per SIMD: two workgroups of 16 waves per CU
 // GINJ: the shot's receivers are not a fused horizontal line (scattered or strided channels, a vertical fibre, directional
@@ -62,10 +63,19 @@ constexpr int kPersistStartLimit = 1 << 15;  // start rendezvous: ~30 ms
 // batch stacked row-wise -- so a row segment's descriptor also names its shot (bits 26..31); the shots' arrays lie at constant
 // strides (PersistArgs::ms), their scalars (source, line of channels) in the ShotDev table of the batched launches.  Everything else
 // -- phases, flags, LDS accumulators, the bodies -- is the single-shot loop's.
-template <int LMASK, bool GINJ = false, bool MS = false>
+// QS (option quiet_skip inside the loop): updates of row segments whose every input is exactly +0 are left out, bit for
+// bit the same arrays.  The tile keeps one word per row segment in LDS -- bit g set: group g of the segment may hold a non-zero value
+// (g = 0 forward velocities, 1 forward stresses, 2 adjoint velocities, 3 adjoint stresses; the forward bits start from the forward
+// pass' maps, the adjoint bits from zero; bits are only ever set) -- and decides per item from its own word and the words of the six
+// row segments its stencils reach (host-built table of their positions in the tile: PersistArgs::q).  Of a segment in ANOTHER tile
+// only a summary is known: the OR over that tile's edge segments, which travels in the top four bits of the tile's phase flag -- the
+// poll that orders the phases reads it anyway -- so next to a tile that holds values the edge segments are computed (never skipped on
+// a guess: a skipped update is one whose inputs are provably +0).  The bits an update reads are written in the OTHER phase only.
+template <int LMASK, bool GINJ = false, bool MS = false, bool QS = false>
 __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistArgs a) {
     extern __shared__ float lds_dyn[];
     __shared__ int next_item, edge_done, abort_flag, start_verdict, cu_slot_s;
+    __shared__ unsigned int nb_sum_s, edge_sum_s;  // QS: OR of the neighbours' summaries (this phase); OR over this tile's edge segments
     const ShotDev &s = a.s;
     const size_t n = a.n;
 #ifdef SEPFWI_PROBES
@@ -156,6 +166,25 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             if constexpr (LMASK & 16) cell[(r++) * acc.stride] = ap.b[c.i];
         }
     }
+    unsigned int *const qs = (unsigned int *)(lds_dyn + (size_t)__builtin_popcount(LMASK) * (size_t)acc.stride);  // QS: one word per row segment
+    if constexpr (QS) {
+        if (threadIdx.x == 0) {
+            nb_sum_s = 0u;
+            edge_sum_s = 0u;
+        }
+        __syncthreads();
+        for (int j = (int)threadIdx.x; j < nst; j += (int)blockDim.x) {
+            const uint32_t d = segs[j];
+            const int z = (int)(d & 0xffffu), xs = (int)((d >> 16) & 0xffu), r = z + 2;
+            unsigned int st0 = 0u;
+            if (z >= 2 && z <= g.nzc - 3) {  // the forward pass' maps (Fields::q: column xs + 1 of qzw words, bit z + 2)
+                const size_t wi = (size_t)(xs + 1) * (size_t)g.qzw + (size_t)(r >> 5);
+                st0 = ((a.q.maps[wi] >> (r & 31)) & 1u) | (((a.q.maps[(size_t)g.qn + wi] >> (r & 31)) & 1u) << 1);
+            }
+            qs[j] = st0;
+            if (j < n_edge && st0) atomicOr(&edge_sum_s, st0);
+        }
+    }
     __syncthreads();
 
     auto grab = [&]() {  // next work item of the workgroup: (phase, segment) in execution order
@@ -208,6 +237,72 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                     } else {
                         stress_body<false, false>(gs, c, f1, m1, md, pc, frame1, z_src, x_src, amp1, adj1, acc1, LineRec{});
                         velocity_adj_body(gs, c, adj1, m1, md, pc, lr1);
+                    }
+                }
+                return;
+            }
+            if constexpr (QS) {
+                // decide for both updates of the item from the tile's words (wave-uniform), apply, mark
+                const int z = c.z, xs = (int)((d >> 16) & 0xffu);
+                const bool on = z >= 2 && z <= g.nzc - 3;
+                typedef const unsigned long long __attribute__((address_space(4))) *nbt_t;
+                const unsigned long long nbw = ((nbt_t)a.q.nbr)[(size_t)tile * (size_t)a.cap + (size_t)j];
+                unsigned int v = 0u;
+                if (lane < 7) {
+                    const unsigned int idx = lane == 6 ? (unsigned int)j : (unsigned int)((nbw >> (8 * lane)) & 0xffull);
+                    v = idx == 0xffu ? 0u : idx == 0xfeu ? nb_sum_s : qs[idx];  // 0xff: no such row segment; 0xfe: another tile's
+                }
+                unsigned int own = 0u, any = 0u;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const unsigned long long bal = __ballot((v >> b) & 1u);
+                    own |= ((bal >> 6) & 1ull) ? (1u << b) : 0u;
+                    any |= (bal & 0x7full) ? (1u << b) : 0u;
+                }
+                bool q1 = false, q2 = false, ni = false;
+                int g1, g2;
+                bool nz1, nz2;
+                if (ph == 0) {  // reverse-time velocity: writes group 0, reads 1, images with 2; adjoint stress: writes 3, reads 2
+                    g1 = 0;
+                    g2 = 3;
+                    if (on) {
+                        q1 = !((own & 1u) | (any & 2u));
+                        ni = !(own & 4u);
+                        q2 = !((own & 8u) | (any & 4u));
+                    }
+                    if (xband) {
+                        nz1 = velocity_body<false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc, q1, ni);
+                        nz2 = stress_adj_body<MemAgent>(gs, c, adj, m, md, pc, q2);
+                    } else {
+                        nz1 = velocity_body<false>(gs, c, f, m, md, pc, frame_t, -1, -1, 0.0f, nullptr, adj, acc, q1, ni);
+                        nz2 = stress_adj_body(gs, c, adj, m, md, pc, q2);
+                    }
+                } else {  // reverse-time stress: writes 1, reads 0, images with 3, the source enters; adjoint velocity: writes 2, reads 3, the residual enters
+                    g1 = 1;
+                    g2 = 2;
+                    if (c.z == s.z_src && c.x == s.x_src) s.stf_grad[it] = -(adj.szz[c.i] + s.src_rxz * adj.sxx[c.i]) * g.dt;  // source_grad
+                    if (on) {
+                        const bool src = z == s.z_src && (s.x_src >> 6) == xs && amp != 0.0f;
+                        const bool rec = lr.n && z == lr.z && xs * BX + BX - 1 >= lr.x0 - 1 && xs * BX <= lr.x0 + lr.n - 1;  // cells lr.x0 - 1 ... lr.x0 + lr.n - 1
+                        q1 = !((own & 2u) | (any & 1u) | (src ? 1u : 0u));
+                        ni = !(own & 8u);
+                        q2 = !((own & 4u) | (any & 8u) | (rec ? 1u : 0u));
+                    }
+                    if (xband) {
+                        nz1 = stress_body<false, false, AccT<LMASK>, MemAgent>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{}, q1, ni);
+                        nz2 = velocity_adj_body<MemAgent>(gs, c, adj, m, md, pc, lr, q2);
+                    } else {
+                        nz1 = stress_body<false, false>(gs, c, f, m, md, pc, frame_t, s.z_src, s.x_src, amp, adj, acc, LineRec{}, q1, ni);
+                        nz2 = velocity_adj_body(gs, c, adj, m, md, pc, lr, q2);
+                    }
+                }
+                if (on) {  // a stored non-zero value sets the segment's bit (and the tile's summary, for an edge segment)
+                    unsigned int set = 0u;
+                    if (!((own >> g1) & 1u) && __ballot(nz1) != 0ull) set |= 1u << g1;
+                    if (!((own >> g2) & 1u) && __ballot(nz2) != 0ull) set |= 1u << g2;
+                    if (set && lane == 0) {
+                        atomicOr(&qs[j], set);
+                        if (j < n_edge) atomicOr(&edge_sum_s, set);
                     }
                 }
                 return;
@@ -280,10 +375,11 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
             // ---- neighbours through the edge part of the previous phase?  then drop what this CU's L1 still holds of their rows
             if (wave == 0 && !nosync) {
                 bool ok = true;
+                unsigned int seen = 0u;
                 if (phase > 0 && lane < nnb) {
                     const unsigned int *pf = a.flags + (size_t)h.nb[lane] * 32;
                     int spins = 0;
-                    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
+                    while (((seen = __hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kFlagPhase) < phase) {
                         __builtin_amdgcn_s_sleep(4);
                         if (++spins > kPersistSpinLimit ||
                             ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -297,6 +393,11 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                         atomicCAS(a.err, 0, 1);
                         abort_flag = 1;
                     }
+                }
+                if constexpr (QS) {  // what the neighbours' edge segments may hold (bits only grow: a summary from a later phase is a superset)
+                    const unsigned int sm = seen >> 28;
+                    const unsigned int u = (__ballot(sm & 1u) ? 1u : 0u) | (__ballot(sm & 2u) ? 2u : 0u) | (__ballot(sm & 4u) ? 4u : 0u) | (__ballot(sm & 8u) ? 8u : 0u);
+                    if (lane == 0) nb_sum_s = u;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -330,7 +431,11 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
 #ifdef SEPFWI_PK_FAULT
                 if (tile == (SEPFWI_PK_FAULT) && phase >= 40u) publish = false;
 #endif
-                if (publish) __hip_atomic_store(my_flag, phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (publish) {
+                    unsigned int word = phase + 1u;
+                    if constexpr (QS) word |= edge_sum_s << 28;  // (every edge item's marks precede its wave's count in `edge_done`: LDS operations are in order)
+                    __hip_atomic_store(my_flag, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 reported = true;
             };
             for (; w < base + nst; w = grab()) {

@@ -106,6 +106,34 @@ std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w
     return "";
 }
 
+std::vector<unsigned long long> make_quiet_neighbours(const PersistPlan &p) {
+    std::vector<unsigned long long> out;
+    if (p.cap > 253) return out;
+    std::vector<int> pos((size_t)p.nzc * p.nseg, -1);  // (row, column) -> position in its tile
+    for (int t = 0; t < p.nwg; t++)
+        for (int j = 0; j < p.hdr[t].n_seg; j++) {
+            const uint32_t d = p.seg[(size_t)t * p.cap + j];
+            pos[(size_t)(d & 0xffffu) * p.nseg + ((d >> 16) & 0xffu)] = j;
+        }
+    out.assign((size_t)p.nwg * p.cap, ~0ull);
+    const int dz[6] = {-2, -1, 1, 2, 0, 0}, dx[6] = {0, 0, 0, 0, -1, 1};
+    for (int t = 0; t < p.nwg; t++)
+        for (int j = 0; j < p.hdr[t].n_seg; j++) {
+            const uint32_t d = p.seg[(size_t)t * p.cap + j];
+            const int z = (int)(d & 0xffffu), xs = (int)((d >> 16) & 0xffu);
+            unsigned long long w = ~0ull;  // bytes 6, 7 stay 0xff
+            for (int q = 0; q < 6; q++) {
+                const int zz = z + dz[q], xx = xs + dx[q];
+                unsigned long long code = 0xffull;
+                if (zz >= 0 && zz < p.nzc && xx >= 0 && xx < p.nseg)
+                    code = p.owner[(size_t)zz * p.nseg + xx] == t ? (unsigned long long)pos[(size_t)zz * p.nseg + xx] : 0xfeull;
+                w = (w & ~(0xffull << (8 * q))) | (code << (8 * q));
+            }
+            out[(size_t)t * p.cap + j] = w;
+        }
+    return out;
+}
+
 std::string make_persist_plan_multishot(int nzc, int nshot, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first,
                                         const PlanCost &cost) {
     if (nshot < 1 || nshot > kPlanMaxShots) return "persist plan: more than " + std::to_string(kPlanMaxShots) + " shots in one launch";

@@ -55,6 +55,12 @@ struct PlanCost {
 std::string make_persist_plan(int nzc, int nseg, int nwg, int nband, int strip_w, PersistPlan *out, bool edge_first = true,
                               const PlanCost &cost = PlanCost());
 
+// Quiet row segments inside the loop (k_bwd_persist<.., QS>): per tile and row segment (in the order of `seg`) the positions in the tile
+// of the six row segments its stencils reach -- rows z-2, z-1, z+1, z+2 of its column, then columns xs-1 and xs+1 of its row -- one
+// byte each in a 64-bit word (byte k = neighbour k): 0xff no such segment (outside the grid), 0xfe a segment of another tile.
+// Empty when a tile has more than 253 row segments (the quiet variant of the loop is then not used).
+std::vector<unsigned long long> make_quiet_neighbours(const PersistPlan &p);
+
 // Several shots in one launch (k_bwd_persist<.., MS>): the plan of the VIRTUAL grid of nshot grids of nzc rows stacked on each other
 // (make_persist_plan with nzc * nshot rows and cost.period = nzc; stencils never cross a shot's first or last two rows, so the
 // neighbour relations the plan finds there only over-synchronise), its descriptors rewritten to  row inside the shot | segment

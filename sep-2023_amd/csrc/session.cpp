@@ -225,6 +225,7 @@ Session::~Session() {
         if (k->d_seg) (void)hipFree(k->d_seg);
         if (k->d_hdr) (void)hipFree(k->d_hdr);
         if (k->d_sync) (void)hipFree(k->d_sync);
+        if (k->d_qnbr) (void)hipFree(k->d_qnbr);
         if (k->d_stf) (void)hipFree(k->d_stf);
         if (k->h_err) (void)hipHostFree(k->h_err);
     }

@@ -200,6 +200,7 @@ class Session {
         uint32_t *d_seg = nullptr;
         TileHdr *d_hdr = nullptr;
         unsigned int *d_sync = nullptr;  // [nwg x 32 flag words | 8 band XCC ids | arrived | err]
+        unsigned long long *d_qnbr = nullptr;  // quiet variant: stencil neighbours of every row segment inside its tile (persist_plan.hpp)
         float *d_stf = nullptr;
         int *h_err = nullptr;            // pinned
         int nwg = 0, threads = 0, lmask = 0, lmask_req = -1, wpc = 0, strip_w = 0, order = -1, wx = -1, wxp = -1, wz = -1, snake = -1, nshots = 0;

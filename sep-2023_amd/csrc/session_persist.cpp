@@ -40,7 +40,7 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
 // nshots = 1: the loop over ONE shot's grid (stream schedule).  nshots > 1: the multi-shot loop of the batched schedule -- the tiles
 // cut the nshots grids stacked on each other (persist_plan.hpp make_persist_plan_multishot).
 bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) {
-    if (opt.bwd_fuse != 4 || opt.quiet_skip != 0) return false;  // (quiet segments are skipped by the per-step launches only)
+    if (opt.bwd_fuse != 4) return false;
     if (k.state >= 0 && k.nshots == nshots && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order &&
         k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask && k.snake == opt.pk_snake) {
         if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
@@ -86,7 +86,8 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
     k.lmask = -1;
     for (int mk : masks) {
         if (opt.pk_lmask != 16 && mk != opt.pk_lmask) continue;
-        const size_t need = (size_t)__builtin_popcount(mk) * (size_t)k.plan.cap * 64 * sizeof(float);
+        // (+ one word per row segment: the quiet-segment states of k_bwd_persist<.., QS>, behind the accumulators)
+        const size_t need = (size_t)__builtin_popcount(mk) * (size_t)k.plan.cap * 64 * sizeof(float) + (size_t)k.plan.cap * sizeof(unsigned int);
         if (need <= per_wg) {
             k.lmask = mk;
             k.lds_bytes = need;
@@ -111,6 +112,14 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
     refree(k.d_seg);
     refree(k.d_hdr);
     refree(k.d_sync);
+    refree(k.d_qnbr);
+    if (!multi) {  // quiet row segments inside the loop: where a segment's stencil neighbours sit in its tile
+        const std::vector<unsigned long long> nb = make_quiet_neighbours(k.plan);
+        if (!nb.empty()) {
+            HIP_OK(dev_malloc((void **)&k.d_qnbr, nb.size() * sizeof(unsigned long long)));
+            HIP_OK(hipMemcpy(k.d_qnbr, nb.data(), nb.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
+    }
     const size_t sync_words = (size_t)k.nwg * 32 + 16;
     HIP_OK(dev_malloc((void **)&k.d_seg, k.plan.seg.size() * sizeof(uint32_t)));
     HIP_OK(dev_malloc((void **)&k.d_hdr, k.plan.hdr.size() * sizeof(TileHdr)));
@@ -208,6 +217,10 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     d.nrec = x.nrec;
     d.src_rxz = (float)x.sh->src_rxz;
     persist_inject(c, x, st, &a.inj);
+    if (x.quiet && k.d_qnbr && !a.inj.lookup) {  // option quiet_skip (fused line of channels, or none): the quiet variant of the loop
+        a.q.maps = x.quiet;
+        a.q.nbr = k.d_qnbr;
+    }
     if (!persist_launch(k, c, a, st)) return false;
     persist_steps_ += (long long)(nSteps - 1);
     return true;
@@ -298,7 +311,7 @@ void Session::persist_check_pass(Persist &k) {
     unsigned int lo = ~0u, hi = 0;
     int t_lo = 0, never = 0;
     for (int t = 0; t < k.nwg; t++) {
-        const unsigned int v = fl[(size_t)t * 32];
+        const unsigned int v = fl[(size_t)t * 32] & 0x0fffffffu;  // (the top four bits: quiet-segment summary)
         if (v < lo) {
             lo = v;
             t_lo = t;

@@ -12,6 +12,8 @@
 
 using namespace sepfwi;
 
+static int check_quiet(const PersistPlan &p);
+
 // cost = nullptr: plain tiling (tiles balanced by count); else by cost (PlanCost: the C-PML strips weigh more)
 static int check(int nzc, int nseg, int nwg, int nband, int sw, const PlanCost *cost = nullptr) {
     PersistPlan p;
@@ -78,6 +80,36 @@ static int check(int nzc, int nseg, int nwg, int nband, int sw, const PlanCost *
         }
         if (hi - lo > (cost ? 2 * wmax : 1)) return 17;
     }
+    return check_quiet(p);
+}
+
+// Quiet-segment neighbour table (make_quiet_neighbours): byte k of a segment's word = position in the tile of its k-th stencil
+// neighbour, 0xfe when another tile owns it, 0xff outside the grid.
+static int check_quiet(const PersistPlan &p) {
+    const std::vector<unsigned long long> nb = make_quiet_neighbours(p);
+    if (p.cap > 253) return nb.empty() ? 0 : 30;
+    if (nb.size() != (size_t)p.nwg * p.cap) return 31;
+    const int dz[6] = {-2, -1, 1, 2, 0, 0}, dx[6] = {0, 0, 0, 0, -1, 1};
+    for (int t = 0; t < p.nwg; t++)
+        for (int j = 0; j < p.hdr[t].n_seg; j++) {
+            const uint32_t d = p.seg[(size_t)t * p.cap + j];
+            const int z = (int)(d & 0xffffu), xs = (int)((d >> 16) & 0xffu);
+            const unsigned long long w = nb[(size_t)t * p.cap + j];
+            if ((w >> 48) != 0xffffull) return 32;
+            for (int q = 0; q < 6; q++) {
+                const int zz = z + dz[q], xx = xs + dx[q];
+                const unsigned int code = (unsigned int)((w >> (8 * q)) & 0xffull);
+                if (zz < 0 || zz >= p.nzc || xx < 0 || xx >= p.nseg) {
+                    if (code != 0xffu) return 33;
+                } else if (p.owner[(size_t)zz * p.nseg + xx] != t) {
+                    if (code != 0xfeu) return 34;
+                } else {
+                    if ((int)code >= p.hdr[t].n_seg) return 35;
+                    const uint32_t e = p.seg[(size_t)t * p.cap + code];
+                    if ((int)(e & 0xffffu) != zz || (int)((e >> 16) & 0xffu) != xx) return 36;
+                }
+            }
+        }
     return 0;
 }
 

@@ -62,11 +62,16 @@ def test_quiet_skip_on_other_geometries(tmp_path, hip_ops, geo):
     lam, mu, den = pb["lame_init"]
     lam = (lam * 1.05).contiguous()
     outs = []
+    nseg_rows = (geo["nz"] + 2 * geo["nPml"]) * ((geo["nx"] + 2 * geo["nPml"] + 63) // 64)
     for q in (0, 1):
-        with P.kernel_options(quiet_skip=q, batch=0):
-            outs.append([t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])])
-    for name, a, b in zip(_NAMES, outs[0], outs[1]):
-        assert np.array_equal(a, b), (geo, name, float(np.abs(a - b).max()), float(np.abs(a).max()))
+        for fuse in (4, 2):      # the persistent loop (its quiet variant: words per row segment in LDS, neighbour summaries in the phase flags) and the two-launch step
+            with P.kernel_options(quiet_skip=q, batch=0, bwd_fuse=fuse):
+                outs.append([t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])])
+                steps = hip_ops.stats(pb["para_fname"], 0)["persist_steps"]
+                assert steps == (2 * (pb["nSteps"] - 1) if fuse == 4 and nseg_rows >= 2048 else 0), (geo, q, fuse, steps)
+    for k in range(1, 4):
+        for name, a, b in zip(_NAMES, outs[0], outs[k]):
+            assert np.array_equal(a, b), (geo, k, name, float(np.abs(a - b).max()), float(np.abs(a).max()))
     assert np.abs(outs[0][1]).max() > 0
 
 
