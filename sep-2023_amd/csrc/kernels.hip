@@ -104,6 +104,8 @@ const OptField kOptFields[] = {
     {"pk_nosync", &KernelOptions::pk_nosync, 0, 1}, {"pk_lock", &KernelOptions::pk_lock, 0, 0x3ff}, {"pk_snake", &KernelOptions::pk_snake, 0, 1},
     // an experiment that lost (EXPERIMENTS #48): the batched schedule's backward sub-batches as ONE multi-shot persistent launch
     {"pk_ms", &KernelOptions::pk_ms, 0, 1},
+    // another one (EXPERIMENTS #49): with quiet_skip on, the persistent loop in its quiet-segment variant instead of the two-launch step
+    {"pk_quiet", &KernelOptions::pk_quiet, 0, 1},
 #endif
 };
 }  // namespace
@@ -235,10 +237,11 @@ void launch_bwd_b(hipStream_t st, const Grid &g0, const KernelOptions &o, Fields
 
 // kind: 0 fused line of channels (or none), 1 general receivers (GINJ), 2 several shots per launch (MS), 3 quiet row segments (QS)
 static void (*persist_kernel(int lmask, int kind))(Grid, const PersistArgs) {
-#ifdef SEPFWI_PROBES  // the multi-shot instances exist in the probe build only: measured slower than the per-step batched launches (EXPERIMENTS #48)
+#ifdef SEPFWI_PROBES  // the multi-shot and the quiet-segment instances exist in the probe build only: both are bit-identical and both measured
+                      // slower than what the shipped library does instead (profiles/EXPERIMENTS.md #48, #49)
 #define SEPFWI_PK(M) (kind == 2 ? k_bwd_persist<M, false, true> : kind == 3 ? k_bwd_persist<M, false, false, true> : kind == 1 ? k_bwd_persist<M, true> : k_bwd_persist<M>)
 #else
-#define SEPFWI_PK(M) (kind == 2 ? nullptr : kind == 3 ? k_bwd_persist<M, false, false, true> : kind == 1 ? k_bwd_persist<M, true> : k_bwd_persist<M>)
+#define SEPFWI_PK(M) (kind >= 2 ? nullptr : kind == 1 ? k_bwd_persist<M, true> : k_bwd_persist<M>)
 #endif
     switch (lmask) {
         case 0: return SEPFWI_PK(0);
@@ -263,6 +266,7 @@ int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes, bool
     for (int kind : {0, 1, 3}) {  // single shot: every instance of the configuration (fused line of channels / general receivers / quiet segments)
         if (multi_shot) kind = 2;
         const void *k = (const void *)persist_kernel(lmask, kind);
+        if (!k && kind == 3) continue;  // (probe build only)
         if (!k) return -1;
         if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
         int per_cu = 0;

@@ -42,6 +42,7 @@ struct KernelOptions {
     int pk_lock = 0;      //   (-DSEPFWI_PROBES builds only) > 0: the two phases of a time step interleaved, timing only (kernels_persist.hpp)
     int pk_snake = 1;     //   (-DSEPFWI_PROBES builds only) 0: every strip of the tiling is walked top-down
     int pk_ms = 0;        //   (-DSEPFWI_PROBES builds only) 1: a backward sub-batch of the batched schedule as ONE multi-shot persistent launch
+    int pk_quiet = 0;     //   (-DSEPFWI_PROBES builds only) 1: with quiet_skip on, the loop's quiet-segment variant instead of the two-launch step
     int pk_prio = 1;      //   1: wave priorities dealt so that the two workgroups of a CU interleave (the arbiter serves the oldest wave first)
     int pk_wx = 150, pk_wxp = 150, pk_wz = 115;  //   tiling by cost: a row segment across the edge of / wholly inside the x C-PML layers, a row inside the z layers, in percent of a plain one
     int img_every = 1;    // imaging condition on every k-th backward step with weight k dt (1 = every step, the reference; k > 1 is an

@@ -40,7 +40,9 @@ bool Session::persist_ready(const Call &c, const ShotCtx &x) {
 // nshots = 1: the loop over ONE shot's grid (stream schedule).  nshots > 1: the multi-shot loop of the batched schedule -- the tiles
 // cut the nshots grids stacked on each other (persist_plan.hpp make_persist_plan_multishot).
 bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) {
-    if (opt.bwd_fuse != 4) return false;
+    // quiet_skip: the two-launch step skips quiet row segments faster than the loop can (fixed tiles: the tiles the wave front is in set
+    // the pace of all, profiles/EXPERIMENTS.md #49); the loop's own quiet variant exists in the -DSEPFWI_PROBES build (option pk_quiet)
+    if (opt.bwd_fuse != 4 || (opt.quiet_skip != 0 && opt.pk_quiet == 0)) return false;
     if (k.state >= 0 && k.nshots == nshots && k.wpc == opt.pk_wpc && k.strip_w == opt.pk_px && k.threads == 64 * opt.pk_waves && k.order == opt.pk_order &&
         k.wx == opt.pk_wx && k.wxp == opt.pk_wxp && k.wz == opt.pk_wz && k.lmask_req == opt.pk_lmask && k.snake == opt.pk_snake) {
         if (k.state == 0 && k.retry_in > 0 && --k.retry_in == 0) k.state = 1;  // a pass did not start because the GPU was busy: try again now
