@@ -59,7 +59,7 @@ def marmousi_style(nz, nx, seed=2023, pert_amp=0.1, sigma_init=40.0):
     return mk(vp), mk(vp0)
 
 
-def setup_problem(workdir, nz, nx, nSteps, n_shots_total, nPml=32, dh=10.0, dt=1.0e-3, f0=10.0, **model_kw):
+def setup_problem(workdir, nz, nx, nSteps, n_shots_total, nPml=32, dh=10.0, dt=1.0e-3, f0=10.0, rec_stride=1, **model_kw):
     from sepfwi import utils as ft
     nPad = ft.nPad_for(nz, nPml)
     nz_pad, nx_pad = nz + 2 * nPml + nPad, nx + 2 * nPml
@@ -67,7 +67,7 @@ def setup_problem(workdir, nz, nx, nSteps, n_shots_total, nPml=32, dh=10.0, dt=1
     survey_fname = os.path.join(workdir, "survey_file.json")
     ft.paraGen(nz_pad, nx_pad, dh, dh, nSteps, dt, f0, nPml, nPad, para_fname, survey_fname, os.path.join(workdir, "Data"))
     src_x = (10 + np.round(np.arange(n_shots_total) * (nx - 21) / max(n_shots_total - 1, 1))).astype(int)
-    rec_x = np.arange(10, nx - 10).astype(int)
+    rec_x = np.arange(10, nx - 10, rec_stride).astype(int)      # rec_stride > 1 (scripts/ab_bench.py): channels that are NOT a line of consecutive cells
     ft.surveyGen(np.full(src_x.shape, 2), src_x, np.full(rec_x.shape, 2), rec_x, survey_fname)
     true, init = marmousi_style(nz, nx, **model_kw)
 

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--nz", type=int, default=1000)
     ap.add_argument("--nx", type=int, default=2000)
     ap.add_argument("--shots", type=int, default=3)
+    ap.add_argument("--rec-stride", type=int, default=1, help="a channel every N cells (N > 1: not a fused line -- k_inject, or the loop's general injection)")
     a = ap.parse_args()
     _native._active = "probes"   # the tuning knobs exist only in the -DSEPFWI_PROBES build of the library
     _native.build(variant="probes")
@@ -36,7 +37,7 @@ def main():
     dev = torch.device("cuda", 0)
     work = tempfile.mkdtemp(prefix="sepfwi_ab_")
     try:
-        pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, a.shots)
+        pb = bench.setup_problem(work, a.nz, a.nx, a.nsteps, a.shots, rec_stride=a.rec_stride)
         lt, mt, dt_ = [t.to(dev) for t in pb["lame_true"]]
         lam, mu, den = [t.to(dev) for t in pb["lame_init"]]
         ids = torch.arange(a.shots, dtype=torch.int32)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: runs at commit f8b3d74 (the probe kernel; scripts/probes/r05_persistent_bwd_probe.patch), not on the current tree.
+# NOTE: runs at commit f8b3d74 (the probe kernel; git history c42f644: scripts/probes/r05_persistent_bwd_probe.patch), not on the current tree.
 # round 5, Step A: the persistent backward time loop WITHOUT cross-tile synchronisation (results wrong, timing only) against
 # the two-launch step.  Variants: accumulators in HBM / in LDS, one or two workgroups per CU, tile shapes.
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: runs at commit f8b3d74 (the probe kernel; scripts/probes/r05_persistent_bwd_probe.patch), not on the current tree.
+# NOTE: runs at commit f8b3d74 (the probe kernel; git history c42f644: scripts/probes/r05_persistent_bwd_probe.patch), not on the current tree.
 # round 5, Step A (third pass): balanced tiles from the host-built plan (137-138 row segments each), three or four
 # accumulators in LDS.  Still no cross-tile synchronisation: results wrong, timing only.
 mkdir -p gpurun_out

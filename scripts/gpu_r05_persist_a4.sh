@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: runs at commit f8b3d74 (the probe kernel; scripts/probes/r05_persistent_bwd_probe.patch), not on the current tree.
+# NOTE: runs at commit f8b3d74 (the probe kernel; git history c42f644: scripts/probes/r05_persistent_bwd_probe.patch), not on the current tree.
 # round 5, Step A (fourth pass): natural (row-major within the strip) order of a tile's segments against edge-first.
 mkdir -p gpurun_out
 timeout -k 10 600 python scripts/ab_bench.py --nsteps 2000 --rounds 2 \

@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: runs on the probe kernel (commit f8b3d74 + the pipelined hand-out; scripts/probes/r05_persistent_bwd_probe.patch + r05_persistent_bwd_probe_pipelined.patch), not on the current tree.
+# NOTE: runs on the probe kernel (commit f8b3d74 + the pipelined hand-out; git history c42f644: scripts/probes/r05_persistent_bwd_probe.patch + r05_persistent_bwd_probe_pipelined.patch), not on the current tree.
 # round 5, Step A (fifth pass): the segment hand-out and the segment descriptor of the NEXT trips fetched while the current one waits for memory.
 mkdir -p gpurun_out
 timeout -k 10 600 python scripts/ab_bench.py --nsteps 2000 --rounds 2 \

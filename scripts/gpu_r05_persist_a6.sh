@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: runs on the probe kernel (commit f8b3d74 + scripts/probes/r05_persistent_bwd_probe_byvalue.patch), not on the current tree.
+# NOTE: runs on the probe kernel (commit f8b3d74 + git history c42f644: scripts/probes/r05_persistent_bwd_probe_byvalue.patch), not on the current tree.
 # round 5, Step A (sixth pass): the argument block passed BY VALUE -- pointers that come from the kernel-argument segment are known to be
 # global, so the bodies use global_load with graded vmcnt waits instead of flat_load with full vmcnt(0) lgkmcnt(0) drains (passes 1-5).
 mkdir -p gpurun_out
