@@ -33,15 +33,15 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_UPDATE_FWDADJ = 184.0 / 3.0   # 60 B fwd + 124 B bwd per cell per step = 61.33 B / cell-update
 BYTES_FWD = 60.0
-# Dominant kernel of the sweep: k_bwd_b (source_grad + reverse-time stress + lambda/mu imaging + adjoint velocity +
-# residual injection).  Of the 124 algorithmic bytes per cell of a backward step it owns the arrays it
-# read-modify-writes and the coefficients / gradients only it needs: szz,sxx,sxz r/w 24 + adjoint vz,vx r/w 16 +
-# lambda,mu,ave_mu 12 + grad lambda,mu r/w 16 = 68 B per cell per launch (k_bwd_a owns the other 56 B: vz,vx r/w 16 +
-# adjoint szz,sxx,sxz r/w 24 + byc_a,byc_b 8 + grad rho r/w 8); DESIGN.md "Kernels and rooflines".
+# Dominant kernel of the sweep: k_bwd_persist, the persistent backward time loop -- ONE launch per shot and backward pass, whose time
+# step IS the backward step of SURVEY.md 8(d): 124 algorithmic bytes per cell (5 forward fields r/w 40, 5 adjoint fields r/w 40,
+# 5 coefficients 20, 3 gradients r/w 24).  `roofline.achieved` = N_c * 124 B / (HIP-event time of the passes / their time steps).
+# Where the loop is not in use (option bwd_fuse=2, a busy GPU) the two-launch step's k_bwd_b is sampled with HIP events instead and
+# charged the arrays it read-modify-writes: szz,sxx,sxz 24 + adjoint vz,vx 16 + lambda,mu,ave_mu 12 + grad lambda,mu 16 = 68 B per cell.
 BYTES_K_BWD_STRESS = 68.0
-# The same apportioning for the other three field kernels (each array charged to the kernel that read-modify-writes it, the
-# coefficients to the kernel that needs them): PMC bytes / these = `roofline.traffic_ratio`.
-ALGO_BYTES_PER_CELL = {"k_bwd_b": 68.0, "k_bwd_a": 56.0, "k_stress_fwd_save": 36.0, "k_velocity_fwd": 24.0}
+# PMC bytes / algorithmic bytes are quoted per STEP only (`roofline.traffic_ratio`: fwd_step against 60 B, bwd_step against 124 B per
+# cell): splitting a step's bytes between its two kernels is an apportioning, not a measurement of either.
+FWD_KERNELS, BWD_KERNELS = ("k_stress_fwd_save", "k_velocity_fwd"), ("k_bwd_a", "k_bwd_b")
 
 
 def marmousi_style(nz, nx, seed=2023, pert_amp=0.1, sigma_init=40.0):
@@ -330,7 +330,7 @@ def main():
             return fwi_ops.backward(lam, mu, den, Stf, world, ids, pb["para_fname"])
 
         from sepfwi import _native
-        _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_b launch
+        _native.check(_native.lib().sepfwi_set_option(b"probe", 61))   # HIP-event timestamps on every 61st k_bwd_b launch (two-launch step only; the loop is timed as a whole)
         for kv in args.option:
             k_, v_ = kv.split("=")
             _native.check(_native.lib().sepfwi_set_option(k_.encode(), int(v_)))
@@ -403,12 +403,13 @@ def main():
                 if tj.get("kernel_source_sha256") == kernel_source_digest():
                     traffic = tj.get("k_bwd_b_bytes_per_launch")
                     traffic_p = tj.get("k_bwd_persist_bytes_per_time_step")     # persistent loop: PMC bytes of a launch / its time steps
-                    # PMC bytes / algorithmic bytes, per kernel and per time step (1.0 = every array touched exactly once)
-                    pmc = {k: tj[k + "_bytes_per_launch"] for k in ALGO_BYTES_PER_CELL if k + "_bytes_per_launch" in tj}
-                    traffic_ratio = {k: round(pmc[k] / (ALGO_BYTES_PER_CELL[k] * pb["n_c"]), 3) for k in pmc}
-                    if "k_bwd_a" in pmc and "k_bwd_b" in pmc:
-                        traffic_ratio["bwd_step"] = round((pmc["k_bwd_a"] + pmc["k_bwd_b"]) / (124.0 * pb["n_c"]), 3)
-                    traffic_ratio["fwd_step"] = round((pmc["k_stress_fwd_save"] + pmc["k_velocity_fwd"]) / (BYTES_FWD * pb["n_c"]), 3)
+                    # PMC bytes / algorithmic bytes per time step (1.0 = every array touched exactly once)
+                    pmc = {k: tj[k + "_bytes_per_launch"] for k in FWD_KERNELS + BWD_KERNELS if k + "_bytes_per_launch" in tj}
+                    traffic_ratio = {}
+                    if all(k in pmc for k in BWD_KERNELS):
+                        traffic_ratio["bwd_step"] = round(sum(pmc[k] for k in BWD_KERNELS) / (124.0 * pb["n_c"]), 3)
+                    if all(k in pmc for k in FWD_KERNELS):
+                        traffic_ratio["fwd_step"] = round(sum(pmc[k] for k in FWD_KERNELS) / (BYTES_FWD * pb["n_c"]), 3)
             if args.mode == "fwdadj" and probe_n > 0:
                 per_step_us = probe_us / probe_n
                 ach = pb["n_c"] * BYTES_K_BWD_STRESS / (per_step_us * 1e-6) / 1e9

@@ -121,6 +121,7 @@ struct InjSeg {  // 32 bytes
     unsigned long long mask[2];  // lanes (cells of the segment) that receive a value: vx, vz
 };
 struct InjArgs {
+    const unsigned char *tile_has;  // [tiles] 1: the tile owns a row segment with targets (the others never look anything up)
     const int *lookup;     // [nzc * nseg] row segment -> InjSeg index or -1
     const InjSeg *segs;
     const float *val;      // [nSteps][ntgt]: the residual folded per target cell (k_inject_values)

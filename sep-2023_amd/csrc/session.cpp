@@ -236,6 +236,7 @@ Session::~Session() {
         (void)hipFree(d.tgt_start);
         (void)hipFree(d.ent_rec);
         (void)hipFree(d.ent_w);
+        if (d.tile_has) (void)hipFree(d.tile_has);
     }
     if (inj_val_) (void)hipFree(inj_val_);
     for (void *p : allocs_) (void)hipFree(p);

@@ -207,6 +207,7 @@ class Session {
         size_t lds_bytes = 0;
         int state = -1;                  // -1 not examined for this configuration, 0 the two-launch step is used, 1 ready
         std::string why;                 // when state == 0
+        int plan_gen = 0;                // counts the tilings built (what depends on one is rebuilt when it changes)
         int retry_in = 0, aborts = 0;    // passes until the loop is tried again after a start rendezvous that failed; how often it did
     } pk_, pk_ms_;  // one shot per launch (stream schedule) / the shots of a backward sub-batch in one launch (batched schedule)
     // adjoint-source injection inside the loop for shots whose receivers are not a fused line: the plan of each such shot (device
@@ -215,7 +216,8 @@ class Session {
         int *lookup = nullptr, *tgt_start = nullptr, *ent_rec = nullptr;
         InjSeg *segs = nullptr;
         float *ent_w = nullptr;
-        int ntgt = 0;
+        unsigned char *tile_has = nullptr;  // per tile of the tiling numbered tile_gen: owns target cells?
+        int ntgt = 0, tile_gen = -1;
     };
     std::map<int, InjDev> inj_;
     float *inj_val_ = nullptr;

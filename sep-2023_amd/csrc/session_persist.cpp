@@ -131,6 +131,7 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
     HIP_OK(hipMemcpy(k.d_seg, k.plan.seg.data(), k.plan.seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(k.d_hdr, k.plan.hdr.data(), k.plan.hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
     k.state = 1;
+    k.plan_gen++;
     k.why.clear();
     return true;
 }
@@ -171,6 +172,20 @@ void Session::persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, In
     }
     launch_inject_values(st, x.res, x.nrec, par_.nSteps, d.tgt_start, d.ent_rec, d.ent_w, d.ntgt, inj_val_);
     launches_++;
+    if (it->second.tile_gen != pk_.plan_gen) {  // which tiles of the CURRENT tiling own target cells (a new tiling: rebuilt)
+        InjDev &dd = it->second;
+        const InjectPlan p = make_inject_plan(x.sh->nrec, x.sh->z_rec.data(), x.sh->x_rec.data(), x.sh->sens.empty() ? nullptr : x.sh->sens.data(),
+                                              par_.fiber != 0, g_.dx * g_.rdz, g_.nzc, g_.nx);
+        std::vector<unsigned char> has((size_t)pk_.nwg, 0);
+        for (size_t sidx = 0; sidx < p.lookup.size(); sidx++)
+            if (p.lookup[sidx] >= 0) has[(size_t)pk_.plan.owner[sidx]] = 1;
+        if (dd.tile_has) (void)hipFree(dd.tile_has);
+        dd.tile_has = nullptr;
+        HIP_OK(dev_malloc((void **)&dd.tile_has, has.size()));
+        HIP_OK(hipMemcpy(dd.tile_has, has.data(), has.size(), hipMemcpyHostToDevice));
+        dd.tile_gen = pk_.plan_gen;
+    }
+    out->tile_has = d.tile_has;
     out->lookup = d.lookup;
     out->segs = d.segs;
     out->val = inj_val_;
