@@ -383,10 +383,13 @@ def main():
             td.all_gather(allr, mine)
             rank_ms = [float(a[0]) for a in allr]
             rank_ar = [float(a[1]) for a in allr]
-            gathered = [None] * world
-            td.all_gather_object(gathered, (rank_loop[0], rank_why[0]))
-            rank_loop = [g[0] for g in gathered]
-            rank_why = [g[1] for g in gathered]
+            # every rank's loop share and reason, as fixed-size tensors through the same all_gather as above (no pickling on the way)
+            enc = (rank_why[0].encode("utf-8", "replace")[:240]).ljust(240, b" ")
+            mine2 = torch.tensor([-1.0 if rank_loop[0] is None else rank_loop[0]] + [float(c) for c in enc], dtype=torch.float64, device=cdev)
+            all2 = [torch.zeros_like(mine2) for _ in range(world)]
+            td.all_gather(all2, mine2)
+            rank_loop = [None if float(a[0]) < 0 else float(a[0]) for a in all2]
+            rank_why = [bytes(int(v) for v in a[1:].tolist()).decode("utf-8", "replace").strip() for a in all2]
 
         passes = 3 if args.mode == "fwdadj" else 1
         updates_per_shot = passes * pb["n_c"] * (args.nsteps - 1)

@@ -12,7 +12,7 @@ struct KernelOptions {
     int bz = 2;           // waves (rows) per block of the field kernels
     int xcd_remap = 1;    // 1: each XCD gets a contiguous band of tiles
     int bwd_fuse = 4;     // backward step: 0 the reference's four kernels (+ k_inject), 2 cross-chain pairs k_bwd_a / k_bwd_b, 4 the
-                          // persistent time loop where the grid and the survey allow it (else 2)
+                          // persistent time loop for every receiver geometry where the grid feeds its tiles (else, and with quiet_skip, 2)
     int line_fuse = 1;    // 1: line receivers are sampled / injected inside the field kernels
     int pair_fwd = 1;     // 1: forward passes of several shots run concurrently (one stream each, or one batched launch)
     int fwd_lanes = 3;    // how many (1..4): 3 x 5 fields + 5 media arrays still sit in the Infinity Cache; 4 lanes lose
@@ -29,7 +29,8 @@ struct KernelOptions {
                           // overlap their fill and drain (+5 % at 1000x500, +16 % on a 100x200 notebook-sized problem with 19 shots)
     int probe = 0;        // >0: time every probe-th k_bwd_b launch with HIP events (bench.py roofline)
     int quiet_skip = 0;   // 1: updates of row segments whose every input is exactly +0 are left out (the fields ahead of the wave front; same bits).
-                          // Used by the forward kernels and the two-launch backward step; line receivers (or none) only
+                          // Used by the forward kernels and the two-launch backward step (which then replaces the loop: EXPERIMENTS #49);
+                          // line receivers (or none) only
     int quiet_rows = 4;   //   rows per wave of the quiet-skipping FORWARD kernels (a quiet wave costs its dispatch whatever it skips)
     int obs_cache_mb = 0; // HBM budget [MB] of the observed-data store (0: unlimited; a parameter-file key of the same name wins)
     // persistent backward time loop (bwd_fuse = 4; kernels.hip k_bwd_persist)
