@@ -331,8 +331,9 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                 if constexpr (GINJ) {
                     // the step's adjoint source at the cells of this segment (rows and columns outside the updated region included:
                     // the adjoint stress update reads them through its stencils); only tiles that own target cells look anything up.
-                    // (Folding the value into the body's own store instead of this read-modify-write was built and is slower, 57.4
-                    // against 54.2 us per backward step: a second inlined copy of the adjoint-velocity body in every instance.)
+                    // (Folding the value into the body's own store instead of this read-modify-write was built twice and is slower:
+                    // 57.4 us per backward step with a second inlined copy of the adjoint-velocity body, 56.4 with one copy and a
+                    // per-lane select -- 44 B of scratch per lane at the 64-register budget -- against 54.2; EXPERIMENTS #50.)
                     typedef const int __attribute__((address_space(4))) *ctab_t;
                     const int slot = inj_tile ? ((ctab_t)a.inj.lookup)[c.z * a.inj.nseg + (int)((d >> 16) & 0xffu)] : -1;
                     if (slot >= 0 && c.x < g.nx) {
