@@ -52,3 +52,55 @@ def test_persistent_loop_random_geometry_is_bit_identical(tmp_path, hip_ops, see
     for name, a, b in zip(("misfit", "gLambda", "gMu", "gDen", "gStf"), got, ref):
         assert np.array_equal(a, b), (desc, name, float(np.abs(a - b).max()), float(np.abs(b).max()))
     assert np.isfinite(ref[0]).all() and np.abs(ref[4]).max() > 0, desc      # (the source gradient is alive from the first backward steps on)
+
+
+_GSEEDS = list(range(int(os.environ.get("SEPFWI_GFUZZ_N", "4"))))
+
+
+@pytest.mark.parametrize("seed", _GSEEDS)
+def test_loop_general_receivers_random_geometry(tmp_path, hip_ops, seed):
+    """Receivers that are not a fused line inside the persistent loop (folded adjoint source, k_bwd_persist<LMASK, GINJ>) against the
+    two-launch step + k_inject on seeded random grids, layer widths and channel sets: strided, scattered with repeats and shared
+    cells, a vertical fibre, directional sensitivities.  The two differ only in the order of the float adds into a cell that several
+    channels reach (k_inject's atomics have none): gradients to 5e-6, misfit exactly.  One-off sweeps: SEPFWI_GFUZZ_N=200."""
+    rng = np.random.default_rng(9000 + seed)
+    nPml = int(rng.integers(6, 25))
+    while True:
+        nz, nx = int(rng.integers(60, 600)), int(rng.integers(120, 1800))
+        segs = (nz + 2 * nPml) * ((nx + 2 * nPml + 63) // 64)
+        if 2200 <= segs <= 12000:
+            break
+    nSteps = int(rng.integers(150, 380))
+    nshots = int(rng.integers(1, 3))
+    kind = int(rng.integers(0, 4))
+    kw = {}
+    if kind == 0:
+        kw = dict(nrec_stride=int(rng.integers(2, 7)), rec_z=int(rng.integers(2, max(3, min(nz - 3, 60)))))
+    elif kind == 1:
+        m = int(rng.integers(1, 60))
+        xs = rng.integers(2, nx - 2, size=m)
+        xs = np.concatenate([xs, xs[: m // 3], xs[: m // 4] + 1])      # repeated channels and neighbours that share a cell
+        kw = dict(rec_x=[int(min(v, nx - 2)) for v in xs], rec_z=int(rng.integers(2, max(3, min(nz - 3, 60)))))
+    elif kind == 2:
+        kw = dict(das_fiber="vertical", nrec_stride=int(rng.integers(1, 4)), src_x=[int(nx // 2 - 20), int(nx // 2 + 30)][:nshots])
+    else:
+        kw = dict(das_sensitivity="random", nrec_stride=int(rng.integers(1, 4)), rec_z=int(rng.integers(3, max(4, min(nz - 4, 60)))))
+    pb = P.make_problem(str(tmp_path), nz=nz, nx=nx, nPml=nPml, nSteps=nSteps, nshots=nshots, hetero=True, seed=seed, f0=float(rng.uniform(10.0, 30.0)), **kw)
+    lt, mt, dt_ = pb["lame_true"]
+    hip_ops.obscalc(lt, mt, dt_, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"], to_store=True)
+    lam, mu, den = pb["lame_init"]
+    lam = (lam * 1.05).contiguous()
+    with P.kernel_options(batch=0, bwd_fuse=2):
+        ref = [t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])]
+    with P.kernel_options(batch=0, bwd_fuse=4):
+        got = [t.numpy().copy() for t in hip_ops.backward(lam, mu, den, pb["Stf"], 1, pb["Shot_ids"], pb["para_fname"])]
+        steps = hip_ops.stats(pb["para_fname"], 0)["persist_steps"]
+    hip_ops.release()
+    desc = dict(seed=seed, nz=nz, nx=nx, nPml=nPml, nSteps=nSteps, nshots=nshots, kind=kind, nrec=pb["nrec"])
+    assert steps == nshots * (nSteps - 1), desc
+    assert got[0][0] == ref[0][0], desc
+    for name, a, b in zip(("gLambda", "gMu", "gDen", "gStf"), got[1:], ref[1:]):
+        if np.abs(b).max() > 0:
+            assert P.rel_l2(a, b) <= 5e-6, (desc, name, P.rel_l2(a, b))
+        else:
+            assert not a.any(), (desc, name)
