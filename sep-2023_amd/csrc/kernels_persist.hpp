@@ -35,6 +35,10 @@
 //     not by count (persist_plan.hpp PlanCost, options pk_wx / pk_wz).
 // Segment descriptors are read through the scalar cache: a vector load of one waits with vmcnt(0), i.e. for the previous row segment's
 // stores as well (2.6 % of the backward step).
+// Instances: k_bwd_persist<LMASK> (a fused line of channels, or none) and <LMASK, GINJ> (any other receiver geometry) are what the
+// shipped library launches.  <.., MS> (several shots per launch), <.., QS> (quiet row segments) and the pk_lock item order are
+// experiments that are bit-identical (MS, QS) and lost on time (profiles/EXPERIMENTS.md #47-#49): they are compiled in the
+// -DSEPFWI_PROBES build only, where their tests and A/B scripts run.
 // ---------------------------------------------------------------------------------------------
 #ifdef SEPFWI_PK_TRACE
 // one-off wave timeline of the loop (build with SEPFWI_HIPCC_FLAGS=-DSEPFWI_PK_TRACE; scripts/gpu_r05_pk_trace.sh, scripts/pk_trace.py):

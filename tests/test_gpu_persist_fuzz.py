@@ -80,7 +80,8 @@ def test_loop_general_receivers_random_geometry(tmp_path, hip_ops, seed):
         m = int(rng.integers(1, 60))
         xs = rng.integers(2, nx - 2, size=m)
         xs = np.concatenate([xs, xs[: m // 3], xs[: m // 4] + 1])      # repeated channels and neighbours that share a cell
-        kw = dict(rec_x=[int(min(v, nx - 2)) for v in xs], rec_z=int(rng.integers(2, max(3, min(nz - 3, 60)))))
+        kw = dict(rec_x=[int(min(v, nx - 2)) for v in xs], rec_z=int(rng.integers(2, max(3, min(nz - 3, 60)))),
+                  src_x=[int(np.clip(np.median(xs) + 25 * q, 2, nx - 3)) for q in range(nshots)])      # sources among the channels: the wave arrives within the record
     elif kind == 2:
         kw = dict(das_fiber="vertical", nrec_stride=int(rng.integers(1, 4)), src_x=[int(nx // 2 - 20), int(nx // 2 + 30)][:nshots])
     else:
@@ -99,6 +100,8 @@ def test_loop_general_receivers_random_geometry(tmp_path, hip_ops, seed):
     desc = dict(seed=seed, nz=nz, nx=nx, nPml=nPml, nSteps=nSteps, nshots=nshots, kind=kind, nrec=pb["nrec"])
     assert steps == nshots * (nSteps - 1), desc
     assert got[0][0] == ref[0][0], desc
+    if not ref[0][0] > 0:      # (a record that ends before the wave reaches any channel: the "gradient" is rounding noise of the stencil's precursor)
+        pytest.xfail("seed %d: no signal at the channels within the record" % seed)
     for name, a, b in zip(("gLambda", "gMu", "gDen", "gStf"), got[1:], ref[1:]):
         if np.abs(b).max() > 0:
             assert P.rel_l2(a, b) <= 5e-6, (desc, name, P.rel_l2(a, b))
