@@ -146,7 +146,8 @@ typedef struct sepfwi_stats {
 int sepfwi_get_stats(const char *para_fname, int gpu_id, sepfwi_stats *out);
 
 /*
- * Why the most recent backward passes of (para_fname, gpu_id) did NOT run in the persistent time loop -- "" while they did (or no
+ * Extension (no counterpart in the reference, whose driver has one way of running a backward step, Src/libCUFD.cu:545-631):
+ * why the most recent backward passes of (para_fname, gpu_id) did NOT run in the persistent time loop -- "" while they did (or no
  * gradient call has asked yet): the grid is too small for the loop's tiles, the configuration cannot be resident at once, the start
  * rendezvous found the GPU busy, ...  Up to len - 1 characters into `why`, always terminated.  For multi-GPU runs: a rank that fell
  * back to per-step launches is 10 % slower than its peers and must be visible (bench.py prints every rank's string).
