@@ -48,6 +48,23 @@ def test_shipped_library_knows_only_the_public_options():
             assert LP.sepfwi_set_option(name.encode(), v) == 0, name
 
 
+def test_status_queries_without_a_session_are_errors_not_crashes(tmp_path):
+    """sepfwi_get_stats / sepfwi_loop_status / sepfwi_debug_field on a parameter file no call has used yet, and with NULL or undersized
+    buffers: SEPFWI_EINVAL with a message (the reference has no such queries; its failures are exit(1), Src/utilities.h:28-36)."""
+    import ctypes as C
+    from sepfwi import _native
+    L = _native.lib()
+    pb = P.make_problem(str(tmp_path), nSteps=20)
+    fn = pb["para_fname"].encode()
+    buf = C.create_string_buffer(64)
+    assert L.sepfwi_loop_status(fn, 0, buf, 64) == -1 and b"no session" in L.sepfwi_last_error()
+    assert L.sepfwi_loop_status(fn, 0, None, 64) == -1 and L.sepfwi_loop_status(fn, 0, buf, 0) == -1 and L.sepfwi_loop_status(None, 0, buf, 64) == -1
+    st = _native.Stats()
+    assert L.sepfwi_get_stats(fn, 0, C.byref(st)) == -1 and b"no session" in L.sepfwi_last_error()
+    out = (C.c_float * 4)()
+    assert L.sepfwi_debug_field(fn, 0, 0, 0, out) == -1
+
+
 def test_library_does_not_link_hipfft():
     """hipFFT is opened with dlopen when the first FFT plan is made (csrc/conditioning.hip FftApi): it is not a DT_NEEDED entry, so
     a ROCm image without it still loads the propagator; the HIP runtime is the only ROCm library the loader must find."""
