@@ -10,5 +10,7 @@ run "500x250 x 16 shots" --nsteps 600 --nz 250 --nx 500 --shots 16 "" "pk_ms=1" 
 run "1000x500 x 12 shots" --nsteps 600 --nz 500 --nx 1000 --shots 12 "" "pk_ms=1" "batch=0"
 run "1500x500 x 6 shots" --nsteps 600 --nz 500 --nx 1500 --shots 6 "" "pk_ms=1" "batch=0"
 run "2000x500 x 3 shots (configs[1] shape, fwd+adj)" --nsteps 1000 --nz 500 "" "batch=1" "batch=1,pk_ms=1"
+run "200x100 x 19 shots, 1500 steps, a channel every third cell (not a fused line: batched k_record / k_inject, one launch per sub-batch)" --nsteps 1500 --nz 100 --nx 200 --shots 19 --rec-stride 3 ""
+run "500x250 x 16 shots, a channel every third cell" --nsteps 600 --nz 250 --nx 500 --shots 16 --rec-stride 3 ""
 echo "== experiment 001 of the reference (101x201, 1501 steps, 19 shots): one gradient evaluation" | tee -a $OUT
 timeout -k 10 300 python scripts/small_grid_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT

@@ -111,6 +111,8 @@ struct ShotDev {
     int comps, nrec;
     float src_rxz;
     unsigned int *quiet;  // null, or the shot's four quiet-segment maps: forward velocity, forward stress, adjoint velocity, adjoint stress
+    const int *rec;       // the shot's channels as flat cell indices (k_record_batch / k_inject_batch: shots whose channels are not a fused line)
+    const float *sens;    // null, or nrec x 3 directional sensitivities
 };
 
 // Adjoint-source injection inside the persistent backward loop for receivers that are not a fused horizontal line (inject_plan.hpp):

@@ -380,6 +380,15 @@ void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const in
                        sens, g.pitch, g.dx * g.rdz);
 }
 
+void launch_record_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, int max_nrec, size_t n, size_t data_len, int column) {
+    if (nb <= 0 || max_nrec <= 0) return;
+    hipLaunchKernelGGL(k_record_batch, dim3((max_nrec + 255) / 256, nb), dim3(256), 0, st, g, shots, n, data_len, column);
+}
+void launch_inject_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, int max_nrec, size_t n, int it) {
+    if (nb <= 0 || max_nrec <= 0) return;
+    hipLaunchKernelGGL(k_inject_batch, dim3((max_nrec + 255) / 256, nb), dim3(256), 0, st, g, shots, n, it);
+}
+
 void launch_inject_values(hipStream_t st, const float *res, int nrec, int nSteps, const int *tgt_start, const int *ent_rec, const float *ent_w, int ntgt,
                           float *val) {
     if (ntgt <= 0 || nSteps <= 0) return;

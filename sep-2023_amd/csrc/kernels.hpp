@@ -87,6 +87,9 @@ void launch_record(hipStream_t st, const Grid &g, Fields f, int nrec, const int 
 // sens: null (straight fibre along x, or along z when g.fiber) or nrec x 3 directional sensitivities (s_xx, s_zz, s_xz)
 void launch_inject(hipStream_t st, const Grid &g, Fields adj, int nrec, const int *rec_idx, const float *res_t,
                    const float *sens = nullptr);
+// batched receivers (one launch for the shots of a batch that are NOT served inside the field kernels): seismogram column / residual column
+void launch_record_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, int max_nrec, size_t n, size_t data_len, int column);
+void launch_inject_batch(hipStream_t st, const Grid &g, const ShotDev *shots, int nb, int max_nrec, size_t n, int it);
 // the residual [it][rec] folded per injection target and time step: val[it][t] = sum over the target's entries of w r[it][rec] (inject_plan.hpp)
 void launch_inject_values(hipStream_t st, const float *res, int nrec, int nSteps, const int *tgt_start, const int *ent_rec, const float *ent_w, int ntgt,
                           float *val);

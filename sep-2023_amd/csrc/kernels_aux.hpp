@@ -64,6 +64,62 @@ __global__ void k_inject(Fields adj, int nrec, const int *__restrict__ rec_idx, 
     }
 }
 
+// Batched forms (one launch for every shot of a batch, blockIdx.y = shot; ShotDev table): on grids small enough for the batched schedule
+// a launch per shot and time step for the receivers alone made a vertical fibre three times slower than a horizontal one.
+__device__ __forceinline__ void record_one(const Grid &g, const Fields &f, int i, int r, float *d_pr, float *d_vx, float *d_vz, float *d_ett, int comps, int fiber,
+                                           const float *sens) {
+    if (comps & 1) d_pr[r] = f.szz[i] + f.sxx[i];
+    const float vx = f.vx[i];
+    if (comps & 2) d_vx[r] = vx;
+    const float vz = f.vz[i];
+    if (comps & 4) d_vz[r] = vz;
+    if (!(comps & 8)) return;
+    if (sens) {
+        const float k = g.dx * g.rdz;
+        const float exx = vx - f.vx[i - 1];
+        const float ezz = (vz - f.vz[i - g.pitch]) * k;
+        const float exz = 0.5f * ((f.vx[i + g.pitch] - vx) * k + (f.vz[i + 1] - vz));
+        d_ett[r] = sens[3 * r] * exx + sens[3 * r + 1] * ezz + sens[3 * r + 2] * exz;
+        return;
+    }
+    d_ett[r] = fiber ? vz - f.vz[i - g.pitch] : vx - f.vx[i - 1];
+}
+// seismogram column `column` of every shot of the batch whose channels are NOT sampled inside k_stress (comps bit 16)
+__global__ void k_record_batch(Grid g, const ShotDev *__restrict__ shots, size_t n, size_t data_len, int column) {
+    const ShotDev &s = shots[blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((s.comps & 16) || r >= s.nrec) return;
+    const Fields f{s.fields, s.fields + n, s.fields + 2 * n, s.fields + 3 * n, s.fields + 4 * n};
+    float *col = s.syn + (size_t)column * (size_t)s.nrec;
+    record_one(g, f, s.rec[r], r, col, col + data_len, col + 2 * data_len, col + 3 * data_len, s.comps, g.fiber, s.sens);
+}
+// residual column `it` of every shot of the batch whose channels are not a fused line (lr_n == 0), as k_inject
+__global__ void k_inject_batch(Grid g, const ShotDev *__restrict__ shots, size_t n, int it) {
+    const ShotDev &s = shots[blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s.lr_n != 0 || r >= s.nrec) return;
+    float *avz = s.adj, *avx = s.adj + n;
+    const int i = s.rec[r], P = g.pitch;
+    const float v = s.res[(size_t)it * (size_t)s.nrec + r], dx_dz = g.dx * g.rdz;
+    if (s.sens) {
+        const float a = s.sens[3 * r] * v, b = s.sens[3 * r + 1] * dx_dz * v, c = 0.5f * s.sens[3 * r + 2] * v;
+        atomicAdd(&avx[i], a);
+        atomicAdd(&avx[i - 1], -a);
+        atomicAdd(&avz[i], b);
+        atomicAdd(&avz[i - P], -b);
+        atomicAdd(&avx[i + P], c * dx_dz);
+        atomicAdd(&avx[i], -(c * dx_dz));
+        atomicAdd(&avz[i + 1], c);
+        atomicAdd(&avz[i], -c);
+    } else if (g.fiber) {
+        atomicAdd(&avz[i], v);
+        atomicAdd(&avz[i - P], -v);
+    } else {
+        atomicAdd(&avx[i], v);
+        atomicAdd(&avx[i - 1], -v);
+    }
+}
+
 // The adjoint source of the persistent loop for general receivers (inject_plan.hpp): one value per target cell and time step,
 //   val[it][t] = sum_e w_e res[it][rec_e]   over the target's entries in channel order
 // -- what k_inject's atomics add to that cell in that step, in a fixed order.  One thread per (target, time step).

@@ -57,6 +57,8 @@ std::vector<ShotDev> Session::batch_table(const Call &c, int Bf, int Bb) {
         d.nrec = x.nrec;
         d.src_rxz = (float)x.sh->src_rxz;
         d.quiet = x.quiet;
+        d.rec = x.rec;
+        d.sens = x.sens;
     }
     HIP_OK(hipMemcpyAsync(d_shots_, tab.data(), tab.size() * sizeof(ShotDev), hipMemcpyHostToDevice, c.st));
     HIP_OK(hipStreamSynchronize(c.st));  // `tab` and `stf_rows` are pageable host memory
@@ -94,21 +96,25 @@ void Session::batched_forward(Call &c, const std::vector<ShotDev> &tab, int is0,
     HIP_OK(hipEventRecord(ev_[0], st));
     for (int k = 0; k < nb; k++) forward_init(cx[k]);
     // the batch as up to three sub-batches on streams of their own (option batch_split)
-    int ns = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nb));
-    for (int k = 0; k < nb; k++)
-        if (!(tab[is0 + k].comps & 16)) ns = 1;  // (general receivers are sampled by launches on the call's stream)
+    const int ns = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nb));
+    auto general = [&](int a0, int a1) {  // a shot in [a0, a1) whose channels are not sampled inside k_stress?
+        for (int k = a0; k < a1; k++)
+            if (!(tab[is0 + k].comps & 16) && tab[is0 + k].nrec > 0) return true;
+        return false;
+    };
     hipStream_t sub[kMaxLanes] = {};
     batch_streams(st, ns, sub);
-    for (int it = 0; it <= nSteps - 2; it++) {
+    for (int it = 0; it <= nSteps - 2; it++)
         for (int q = 0; q < ns; q++) {
             const int a0 = (int)((long long)nb * q / ns), a1 = (int)((long long)nb * (q + 1) / ns);
             launch_stress_fwd_batch(sub[q], g_, opt, d_shots_ + is0 + a0, a1 - a0, md_, pc_, cells_, data_len_, it, c.src_scale, c.with_adj);
             launch_velocity_fwd_batch(sub[q], g_, opt, d_shots_ + is0 + a0, a1 - a0, md_, pc_, cells_);
             launches_ += 2;
+            if (general(a0, a1)) {  // general receivers: ONE launch samples the new state of the sub-batch's shots into column it + 1
+                launch_record_batch(sub[q], g_, d_shots_ + is0 + a0, a1 - a0, survey_.max_nrec, cells_, data_len_, it + 1);
+                launches_++;
+            }
         }
-        for (int k = 0; k < nb; k++)
-            if (!(tab[is0 + k].comps & 16)) record_column(cx[k], it + 1);  // general receivers: sample the new state into column it+1
-    }
     batch_join(st, ns);
     for (int k = 0; k < nb; k++)
         if (tab[is0 + k].comps & 16) record_column(cx[k], nSteps - 1);
@@ -134,8 +140,11 @@ void Session::batched_backward(Call &c, const std::vector<ShotDev> &tab, int fir
     for (int k = 0; k < nbb; k++)
         if (cx[k].quiet) HIP_OK(hipMemsetAsync(cx[k].quiet + 2 * (size_t)g.qn, 0, 2 * (size_t)g.qn * sizeof(unsigned int), st));
     int nsb = std::max(1, std::min(std::min(opt.batch_split, (int)kMaxLanes - 1), nbb));  // sub-batches on streams of their own, as in the forward loop
-    for (int k = 0; k < nbb; k++)
-        if (tab[first + k].lr_n == 0) nsb = 1;  // (k_inject runs on the call's stream)
+    auto general = [&](int a0, int a1) {  // a shot in [a0, a1) whose residual is not injected inside k_bwd_b?
+        for (int k = a0; k < a1; k++)
+            if (tab[first + k].lr_n == 0 && tab[first + k].nrec > 0) return true;
+        return false;
+    };
     // An experiment that lost, kept in the -DSEPFWI_PROBES build (option pk_ms; profiles/EXPERIMENTS.md #48): the whole sub-batch as ONE
     // persistent launch (the multi-shot loop, session_persist.cpp) where every shot's channels are a fused line (or absent).  On every
     // grid that takes the batched schedule the per-step launches below are faster, also against the loop without any synchronisation.
@@ -155,14 +164,11 @@ void Session::batched_backward(Call &c, const std::vector<ShotDev> &tab, int fir
             launch_bwd_b_batch(sub[q], gs, opt, d_shots_ + first + a0, a1 - a0, md_, pc_, n, it, c.src_scale, (ev && q == 0) ? ev[0] : nullptr,
                                (ev && q == 0) ? ev[1] : nullptr);
             launches_ += 2;
-        }
-        for (int k = 0; k < nbb; k++)
-            if (tab[first + k].lr_n == 0) {
-                const ShotCtx &x = cx[k];
-                const Fields adj = Fields{bl_[k].bwd + 8 * n, bl_[k].bwd + 9 * n, bl_[k].bwd + 10 * n, bl_[k].bwd + 11 * n, bl_[k].bwd + 12 * n};
-                launch_inject(st, g, adj, x.nrec, x.rec, x.res + (size_t)it * x.nrec, x.sens);
+            if (general(a0, a1)) {  // res_injection_exx / _ezz for the sub-batch's shots whose channels are not a fused line: ONE launch
+                launch_inject_batch(sub[q], g, d_shots_ + first + a0, a1 - a0, survey_.max_nrec, n, it);
                 launches_++;
             }
+        }
     }
     batch_join(st, nsb);
     HIP_OK(hipEventRecord(ev_[3], st));
