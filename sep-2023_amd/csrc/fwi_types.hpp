@@ -170,7 +170,7 @@ struct PersistArgs {
     int nosync;              // -DSEPFWI_PROBES builds, timing experiments only: no waits, no flags, no agent-scope accesses (results wrong)
     int lock;                // -DSEPFWI_PROBES builds, timing experiments only: phases interleaved (option pk_lock)
     int prio;                // 1: wave priorities interleave the CU's two workgroups (kernels.hip)
-    InjArgs inj;             // k_bwd_persist<LMASK, true>: general receivers (else unused)
+    const InjArgs *injp;     // k_bwd_persist<LMASK, true>: general receivers -- the tables of the shot's adjoint source, in device memory (else null)
     MultiShot ms;            // k_bwd_persist<LMASK, false, true>: the shots of the launch (else unused)
     QuietArgs q;             // k_bwd_persist<LMASK, false, false, true>: quiet row segments (else unused)
 };

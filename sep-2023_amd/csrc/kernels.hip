@@ -280,7 +280,7 @@ int persist_config_check(int nwg, int threads, int lmask, size_t lds_bytes, bool
 int launch_bwd_persist(hipStream_t st, const Grid &g0, const KernelOptions &o, const PersistArgs &args, int nwg, int threads, int lmask,
                        size_t lds_bytes, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const Grid g = tiled(g0, o, 1);
-    auto k = persist_kernel(lmask, args.ms.nshot > 0 ? 2 : args.q.maps != nullptr ? 3 : args.inj.lookup != nullptr ? 1 : 0);
+    auto k = persist_kernel(lmask, args.ms.nshot > 0 ? 2 : args.q.maps != nullptr ? 3 : args.injp != nullptr ? 1 : 0);
     if (!k) return -1;
 #ifdef SEPFWI_PK_TRACE
     {

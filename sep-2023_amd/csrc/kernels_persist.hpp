@@ -136,7 +136,7 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
     if (start_verdict != (int)kPersistGo) return;
     const int cu_slot = cu_slot_s;
     bool inj_tile = false;  // GINJ: does this tile own cells of the adjoint source?
-    if constexpr (GINJ) inj_tile = __builtin_amdgcn_readfirstlane((int)a.inj.tile_has[tile]) != 0;
+    if constexpr (GINJ) inj_tile = __builtin_amdgcn_readfirstlane((int)a.injp->tile_has[tile]) != 0;
     auto set_prio = [&](int p) {  // (the instruction takes an immediate)
         switch (p & 3) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -334,25 +334,31 @@ __global__ __launch_bounds__(MAXT, 8) void k_bwd_persist(Grid g, const PersistAr
                 }
                 if constexpr (GINJ) {
                     // the step's adjoint source at the cells of this segment (rows and columns outside the updated region included:
-                    // the adjoint stress update reads them through its stencils); only tiles that own target cells look anything up.
+                    // the adjoint stress update reads them through its stencils).  Only tiles that own target cells look anything up,
+                    // and the tables are reached through ONE pointer (a.injp), read in this rare branch: six more pointers alive in
+                    // the loop cost every row segment of every tile scalar spills.
                     // (Folding the value into the body's own store instead of this read-modify-write was built twice and is slower:
                     // 57.4 us per backward step with a second inlined copy of the adjoint-velocity body, 56.4 with one copy and a
                     // per-lane select -- 44 B of scratch per lane at the 64-register budget -- against 54.2; EXPERIMENTS #50.)
-                    typedef const int __attribute__((address_space(4))) *ctab_t;
-                    const int slot = inj_tile ? ((ctab_t)a.inj.lookup)[c.z * a.inj.nseg + (int)((d >> 16) & 0xffu)] : -1;
-                    if (slot >= 0 && c.x < g.nx) {
-                        const InjSeg q = a.inj.segs[slot];
-                        const float *val_t = a.inj.val + (size_t)it * (size_t)a.inj.ntgt;
-                        const unsigned long long below = (1ull << lane) - 1ull;
-                        if ((q.mask[0] >> lane) & 1ull) {
-                            const float v = val_t[q.base[0] + __popcll(q.mask[0] & below)];
-                            if (xband) MemAgent::st(&adj.vx[c.i], MemAgent::ld(&adj.vx[c.i]) + v);
-                            else adj.vx[c.i] += v;
-                        }
-                        if ((q.mask[1] >> lane) & 1ull) {
-                            const float v = val_t[q.base[1] + __popcll(q.mask[1] & below)];
-                            if (xband) MemAgent::st(&adj.vz[c.i], MemAgent::ld(&adj.vz[c.i]) + v);
-                            else adj.vz[c.i] += v;
+                    if (inj_tile) {
+                        typedef const InjArgs __attribute__((address_space(4))) *inj_t;
+                        typedef const int __attribute__((address_space(4))) *ctab_t;
+                        const inj_t ia = (inj_t)a.injp;
+                        const int slot = ((ctab_t)ia->lookup)[c.z * ia->nseg + (int)((d >> 16) & 0xffu)];
+                        if (slot >= 0 && c.x < g.nx) {
+                            const InjSeg q = ia->segs[slot];
+                            const float *val_t = ia->val + (size_t)it * (size_t)ia->ntgt;
+                            const unsigned long long below = (1ull << lane) - 1ull;
+                            if ((q.mask[0] >> lane) & 1ull) {
+                                const float v = val_t[q.base[0] + __popcll(q.mask[0] & below)];
+                                if (xband) MemAgent::st(&adj.vx[c.i], MemAgent::ld(&adj.vx[c.i]) + v);
+                                else adj.vx[c.i] += v;
+                            }
+                            if ((q.mask[1] >> lane) & 1ull) {
+                                const float v = val_t[q.base[1] + __popcll(q.mask[1] & below)];
+                                if (xband) MemAgent::st(&adj.vz[c.i], MemAgent::ld(&adj.vz[c.i]) + v);
+                                else adj.vz[c.i] += v;
+                            }
                         }
                     }
                 }

@@ -237,6 +237,7 @@ Session::~Session() {
         (void)hipFree(d.ent_rec);
         (void)hipFree(d.ent_w);
         if (d.tile_has) (void)hipFree(d.tile_has);
+        if (d.d_args) (void)hipFree(d.d_args);
     }
     if (inj_val_) (void)hipFree(inj_val_);
     for (void *p : allocs_) (void)hipFree(p);

@@ -115,7 +115,7 @@ class Session {
     bool backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L);
     bool batched_backward_persistent(Call &c, const std::vector<ShotDev> &tab, int first, int nbb);
     bool persist_launch(Persist &k, Call &c, PersistArgs &a, hipStream_t st);
-    void persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, InjArgs *out);
+    const InjArgs *persist_inject(const Call &c, const ShotCtx &x, hipStream_t st);
     void persist_demote(Persist &k, const std::string &why, int retry_in);
     void persist_check_pass(Persist &k);
     hipEvent_t *probe_pair(Call &c, int it);
@@ -217,6 +217,7 @@ class Session {
         InjSeg *segs = nullptr;
         float *ent_w = nullptr;
         unsigned char *tile_has = nullptr;  // per tile of the tiling numbered tile_gen: owns target cells?
+        InjArgs h_args{}, *d_args = nullptr;  // what the kernel reads through PersistArgs::injp
         int ntgt = 0, tile_gen = -1;
     };
     std::map<int, InjDev> inj_;

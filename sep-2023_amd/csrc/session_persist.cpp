@@ -139,9 +139,8 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
 // Adjoint source of a shot whose receivers are not a fused horizontal line (strided or scattered channels, a vertical fibre,
 // directional sensitivities): the injection plan of the shot (built once per session and shot, inject_plan.hpp) and the residual of
 // THIS pass folded per target cell and time step (one launch).  Fills a.inj; leaves it empty for a fused line or no receivers.
-void Session::persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, InjArgs *out) {
-    *out = InjArgs{};
-    if (x.nrec == 0 || (x.line.n > 0 && c.opt.line_fuse != 0)) return;
+const InjArgs *Session::persist_inject(const Call &c, const ShotCtx &x, hipStream_t st) {
+    if (x.nrec == 0 || (x.line.n > 0 && c.opt.line_fuse != 0)) return nullptr;
     auto it = inj_.find(x.id);
     if (it == inj_.end()) {
         const Shot &sh = *x.sh;
@@ -185,12 +184,16 @@ void Session::persist_inject(const Call &c, const ShotCtx &x, hipStream_t st, In
         HIP_OK(hipMemcpy(dd.tile_has, has.data(), has.size(), hipMemcpyHostToDevice));
         dd.tile_gen = pk_.plan_gen;
     }
-    out->tile_has = d.tile_has;
-    out->lookup = d.lookup;
-    out->segs = d.segs;
-    out->val = inj_val_;
-    out->ntgt = d.ntgt;
-    out->nseg = (g_.nx + 63) / 64;
+    InjDev &dd = it->second;  // the kernel reaches the tables through ONE pointer: this block, in device memory
+    dd.h_args.tile_has = d.tile_has;
+    dd.h_args.lookup = d.lookup;
+    dd.h_args.segs = d.segs;
+    dd.h_args.val = inj_val_;
+    dd.h_args.ntgt = d.ntgt;
+    dd.h_args.nseg = (g_.nx + 63) / 64;
+    if (!dd.d_args) HIP_OK(dev_malloc((void **)&dd.d_args, sizeof(InjArgs)));
+    HIP_OK(hipMemcpyAsync(dd.d_args, &dd.h_args, sizeof(InjArgs), hipMemcpyHostToDevice, st));  // (h_args lives in the session's map: valid until the copy has run)
+    return dd.d_args;
 }
 
 std::string Session::loop_status() {
@@ -233,8 +236,8 @@ bool Session::backward_persistent(Call &c, const ShotCtx &x, const BwdLane &L) {
     d.lr_n = x.line.n;
     d.nrec = x.nrec;
     d.src_rxz = (float)x.sh->src_rxz;
-    persist_inject(c, x, st, &a.inj);
-    if (x.quiet && k.d_qnbr && !a.inj.lookup) {  // option quiet_skip (fused line of channels, or none): the quiet variant of the loop
+    a.injp = persist_inject(c, x, st);
+    if (x.quiet && k.d_qnbr && !a.injp) {  // option quiet_skip (fused line of channels, or none): the quiet variant of the loop
         a.q.maps = x.quiet;
         a.q.nbr = k.d_qnbr;
     }
