@@ -96,7 +96,7 @@ const OptField kOptFields[] = {
     {"batch_order", &KernelOptions::batch_order, 0, 1}, {"batch_split", &KernelOptions::batch_split, 1, 3},
     {"quiet_rows", &KernelOptions::quiet_rows, 1, 16},
     {"pk_lmask", &KernelOptions::pk_lmask, 0, 31},  {"pk_wpc", &KernelOptions::pk_wpc, 1, 4},
-    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 1},
+    {"pk_px", &KernelOptions::pk_px, 1, 64},         {"pk_waves", &KernelOptions::pk_waves, 4, 16}, {"pk_order", &KernelOptions::pk_order, 0, 2},
     {"pk_prio", &KernelOptions::pk_prio, 0, 3}, {"pk_wx", &KernelOptions::pk_wx, 25, 400}, {"pk_wxp", &KernelOptions::pk_wxp, 25, 400}, {"pk_wz", &KernelOptions::pk_wz, 25, 400},
     // timing experiments only -- WRONG results: no synchronisation between tiles; phases of a time step interleaved (pk_lock: bits 0-7 the
     // distance D in row segments by which phase B trails phase A, 0x100 alternate walk direction per time step, 0x200 no barrier per step);

@@ -38,7 +38,9 @@ struct KernelOptions {
     int pk_wpc = 2;       //   workgroups (16 waves each) per CU
     int pk_px = 3;        //   strip width of the tiling in row segments (persist_plan.hpp)
     int pk_waves = 16;    //   waves per workgroup
-    int pk_order = 1;     //   1: edge segments first in every phase (the flag goes out early), 0: strip order, the flag goes out at the end of the phase
+    int pk_order = 2;     //   1: edge segments first in every phase (the flag goes out early), 0: strip order, the flag goes out at the end of the phase;
+                          //   2: by tile size -- strip order from 56 row segments per tile on (its locality wins: -2.5 % at the headline's 69, -3.6 % at 100),
+                          //   edge-first below (the early flag wins: +2 % for strip order at 36), profiles/EXPERIMENTS.md #52
     int pk_nosync = 0;    //   (-DSEPFWI_PROBES builds only) 1: no synchronisation between tiles -- WRONG RESULTS, timing experiments
     int pk_lock = 0;      //   (-DSEPFWI_PROBES builds only) > 0: the two phases of a time step interleaved, timing only (kernels_persist.hpp)
     int pk_snake = 1;     //   (-DSEPFWI_PROBES builds only) 0: every strip of the tiling is walked top-down

@@ -79,8 +79,11 @@ bool Session::persist_prepare(Persist &k, const KernelOptions &opt, int nshots) 
     cost.w_xpure = opt.pk_wxp;
     cost.w_zpml = opt.pk_wz;
     cost.snake = opt.pk_snake != 0;
-    k.why = multi ? make_persist_plan_multishot(g_.nzc, nshots, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost)
-                       : make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, opt.pk_order != 0, cost);
+    // order of a tile's row segments inside a phase: edge segments first (the phase flag goes out early) or the strip order of the walk
+    // (better locality, the flag goes out at the end); by default by tile size (KernelOptions::pk_order)
+    const bool edge_first = opt.pk_order == 1 || (opt.pk_order == 2 && (long long)g_.nzc * nshots * nseg < 56LL * k.nwg);
+    k.why = multi ? make_persist_plan_multishot(g_.nzc, nshots, nseg, k.nwg, nband, opt.pk_px, &k.plan, edge_first, cost)
+                       : make_persist_plan(g_.nzc, nseg, k.nwg, nband, opt.pk_px, &k.plan, edge_first, cost);
     if (!k.why.empty()) return false;
     // accumulators in LDS: as many as fit beside the other workgroups of the CU (lam, mu, xz, a, b in that order)
     const size_t per_wg = lds_cu / (size_t)opt.pk_wpc - 256;

@@ -109,7 +109,7 @@ def rel_l2(a, b):
 
 # defaults of struct KernelOptions (csrc/kernels.hpp); `probe` is bench.py's business
 OPTION_DEFAULTS = dict(bz=2, xcd_remap=1, bwd_fuse=4, line_fuse=1, pair_fwd=1, fwd_lanes=3, early=0, rho_fly=1, amu_fly=1,
-                       rk_lazy=1, batch=2, batch_f=0, batch_b=0, batch_mb=200, batch_order=1, batch_split=2, img_every=1, obs_cache_mb=0, quiet_skip=0, quiet_rows=4, pk_lmask=16, pk_wpc=2, pk_px=3, pk_nosync=0, pk_lock=0, pk_snake=1, pk_ms=0, pk_quiet=0, pk_waves=16, pk_order=1, pk_prio=1, pk_wx=150, pk_wxp=150, pk_wz=115)
+                       rk_lazy=1, batch=2, batch_f=0, batch_b=0, batch_mb=200, batch_order=1, batch_split=2, img_every=1, obs_cache_mb=0, quiet_skip=0, quiet_rows=4, pk_lmask=16, pk_wpc=2, pk_px=3, pk_nosync=0, pk_lock=0, pk_snake=1, pk_ms=0, pk_quiet=0, pk_waves=16, pk_order=2, pk_prio=1, pk_wx=150, pk_wxp=150, pk_wz=115)
 
 
 def _needs_probes(opts):
