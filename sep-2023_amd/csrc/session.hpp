@@ -216,6 +216,7 @@ class Session {
         int *lookup = nullptr, *tgt_start = nullptr, *ent_rec = nullptr;
         InjSeg *segs = nullptr;
         float *ent_w = nullptr;
+        std::vector<int> target_segs;       // row segments (z * nseg + xs) that hold target cells
         unsigned char *tile_has = nullptr;  // per tile of the tiling numbered tile_gen: owns target cells?
         InjArgs h_args{}, *d_args = nullptr;  // what the kernel reads through PersistArgs::injp
         int ntgt = 0, tile_gen = -1;

@@ -161,6 +161,8 @@ const InjArgs *Session::persist_inject(const Call &c, const ShotCtx &x, hipStrea
         up(&d.tgt_start, p.tgt_start);
         up(&d.ent_rec, p.ent_rec);
         up(&d.ent_w, p.ent_w);
+        for (size_t sidx = 0; sidx < p.lookup.size(); sidx++)
+            if (p.lookup[sidx] >= 0) d.target_segs.push_back((int)sidx);  // (which tiles own them depends on the tiling: below)
         it = inj_.emplace(x.id, d).first;
     }
     const InjDev &d = it->second;
@@ -176,11 +178,8 @@ const InjArgs *Session::persist_inject(const Call &c, const ShotCtx &x, hipStrea
     launches_++;
     if (it->second.tile_gen != pk_.plan_gen) {  // which tiles of the CURRENT tiling own target cells (a new tiling: rebuilt)
         InjDev &dd = it->second;
-        const InjectPlan p = make_inject_plan(x.sh->nrec, x.sh->z_rec.data(), x.sh->x_rec.data(), x.sh->sens.empty() ? nullptr : x.sh->sens.data(),
-                                              par_.fiber != 0, g_.dx * g_.rdz, g_.nzc, g_.nx);
         std::vector<unsigned char> has((size_t)pk_.nwg, 0);
-        for (size_t sidx = 0; sidx < p.lookup.size(); sidx++)
-            if (p.lookup[sidx] >= 0) has[(size_t)pk_.plan.owner[sidx]] = 1;
+        for (int sidx : dd.target_segs) has[(size_t)pk_.plan.owner[(size_t)sidx]] = 1;
         if (dd.tile_has) (void)hipFree(dd.tile_has);
         dd.tile_has = nullptr;
         HIP_OK(dev_malloc((void **)&dd.tile_has, has.size()));
